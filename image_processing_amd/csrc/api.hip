@@ -1,0 +1,848 @@
+// C ABI of libimgproc_hip (include/imgproc.h): context, pipeline plan, streaming slots, batch
+// paths and single-stage entry points.  Host-side only; the kernels are in kernels.hip / fused.hip.
+// No CPU fallback anywhere: if HIP fails, the call fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/imgproc.h"
+#include "fused.h"
+#include "kernels.h"
+
+#define IMGPROC_API extern "C" __attribute__((visibility("default")))
+
+using ipk::u8;
+
+namespace {
+
+struct Slot {
+    u8 *h_in = nullptr;  // pinned staging (tight rows)
+    u8 *d_raw = nullptr, *d_a = nullptr, *d_b = nullptr, *d_bgr = nullptr, *d_t = nullptr;
+    u8 *d_thresh = nullptr, *d_mask = nullptr, *d_m0 = nullptr, *d_m1 = nullptr, *d_masked = nullptr;
+    unsigned long long *d_mom = nullptr, *h_mom = nullptr;
+    hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    int w = 0, h = 0;
+    bool in_flight = false, has_frame = false;
+    const u8 *blur_ptr = nullptr, *hsv_ptr = nullptr, *bgr_ptr = nullptr;  // where each kept stage lives
+    size_t bgr_stride = 0;
+};
+
+struct Plan {
+    imgproc_pipeline pipe{};
+    std::vector<std::vector<u8>> custom;  // deep copies of custom elements
+    ipk::Taps pre{}, post{};
+    ipk::Element elems[IMGPROC_MAX_MORPH];
+    ipk::Bounds bounds{};
+    ipf::FusedPlan fused{};
+    bool fused_ok = false;
+};
+
+}  // namespace
+
+struct imgproc_ctx {
+    imgproc_config cfg{};
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    int *d_tables = nullptr;
+    std::vector<Slot> slots;
+    Plan plan;
+    unsigned long long *d_mom_batch = nullptr, *h_mom_batch = nullptr;
+    u8 *d_s0 = nullptr, *d_s1 = nullptr;  // scratch for single-stage calls (max frame, 3 ch)
+    unsigned long long *d_s_mom = nullptr;
+    bool profiling = false;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    bool prof_valid = false;
+    int prof_launches = 0;
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail(imgproc_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                     \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail((c), e_ == hipErrorOutOfMemory ? IMGPROC_ENOMEM : IMGPROC_EHIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                         \
+    } while (0)
+
+// --- host-side restatements the plan needs -------------------------
+int gaussian_taps(int k, int *taps)
+{
+    if (k < 1 || !(k & 1) || k > IMGPROC_MAX_KSIZE) return IMGPROC_EINVAL;
+    switch (k) {  // OpenCV's fixed table for sigma<=0, k<=7
+    case 1: taps[0] = 256; return 0;
+    case 3: { const int t[] = {64, 128, 64}; memcpy(taps, t, sizeof t); return 0; }
+    case 5: { const int t[] = {16, 64, 96, 64, 16}; memcpy(taps, t, sizeof t); return 0; }
+    case 7: { const int t[] = {8, 28, 56, 72, 56, 28, 8}; memcpy(taps, t, sizeof t); return 0; }
+    default: break;
+    }
+    const long double sigma = ((k - 1) * 0.5L - 1.0L) * 0.3L + 0.8L;
+    std::vector<long double> g(k);
+    long double tot = 0;
+    for (int i = 0; i < k; i++) {
+        long double x = i - (k - 1) * 0.5L;
+        tot += g[i] = expl(-0.5L * x * x / (sigma * sigma));
+    }
+    long double carry = 0;  // error diffusion toward the centre tap
+    int used = 0;
+    for (int i = 0; i < k / 2; i++) {
+        long double want = g[i] / tot * 256.0L + carry;
+        long long q = llrintl(want);
+        carry = want - (long double)q;
+        taps[i] = taps[k - 1 - i] = (int)q;
+        used += 2 * (int)q;
+    }
+    taps[k / 2] = 256 - used;
+    return 0;
+}
+
+int make_element(const imgproc_morph &m, const u8 *custom, ipk::Element &e)
+{
+    if (m.kw < 1 || m.kh < 1 || m.kw > IMGPROC_MAX_KSIZE || m.kh > IMGPROC_MAX_KSIZE) return IMGPROC_EINVAL;
+    if (m.kind != IMGPROC_ERODE && m.kind != IMGPROC_DILATE) return IMGPROC_EINVAL;
+    e.kw = m.kw;
+    e.kh = m.kh;
+    e.ax = m.anchor_x < 0 ? m.kw / 2 : m.anchor_x;
+    e.ay = m.anchor_y < 0 ? m.kh / 2 : m.anchor_y;
+    if (e.ax >= m.kw || e.ay >= m.kh) return IMGPROC_EINVAL;
+    std::vector<u8> bits((size_t)m.kw * m.kh);
+    if (m.shape == IMGPROC_CUSTOM) {
+        if (!custom) return IMGPROC_EINVAL;
+        memcpy(bits.data(), custom, bits.size());
+    } else {
+        int rc = imgproc_structuring_element(m.shape, m.kw, m.kh, bits.data());
+        if (rc) return rc;
+    }
+    bool all = true;
+    for (int j = 0; j < m.kh; j++) {
+        uint32_t r = 0;
+        for (int i = 0; i < m.kw; i++)
+            if (bits[(size_t)j * m.kw + i]) r |= 1u << i;
+            else all = false;
+        e.rows[j] = r;
+    }
+    for (int j = m.kh; j < 31; j++) e.rows[j] = 0;
+    e.is_rect = all ? 1 : 0;
+    return 0;
+}
+
+void make_bounds(int n, const int32_t (*lo)[3], const int32_t (*hi)[3], ipk::Bounds &b)
+{
+    b.n = n;
+    for (int r = 0; r < n; r++)
+        for (int c = 0; c < 3; c++) {
+            long l = lo[r][c], u = hi[r][c];
+            if (l > u || l > 255 || u < 0) {
+                b.lo[r][c] = 1;  // empty interval: never matches
+                b.hi[r][c] = 0;
+            } else {
+                b.lo[r][c] = (u8)(l < 0 ? 0 : l);
+                b.hi[r][c] = (u8)(u > 255 ? 255 : u);
+            }
+        }
+}
+
+void finish_moments(const unsigned long long *m, imgproc_moments &o)
+{
+    o.m00 = m[0]; o.m10 = m[1]; o.m01 = m[2]; o.m20 = m[3]; o.m11 = m[4]; o.m02 = m[5];
+    o.found = m[0] != 0;
+    o.reserved = 0;
+    if (o.found) {
+        o.cx = (double)m[1] / (double)m[0];
+        o.cy = (double)m[2] / (double)m[0];
+        long double n = (long double)m[0];
+        long double mu20 = (long double)m[3] - (long double)m[1] * (long double)m[1] / n;
+        long double mu02 = (long double)m[5] - (long double)m[2] * (long double)m[2] / n;
+        long double mu11 = (long double)m[4] - (long double)m[1] * (long double)m[2] / n;
+        o.theta = 0.5 * std::atan2((double)(2 * mu11), (double)(mu20 - mu02));
+    } else {
+        o.cx = o.cy = -1.0;
+        o.theta = 0.0;
+    }
+}
+
+void free_slot(Slot &s)
+{
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_mom) (void)hipHostFree(s.h_mom);
+    u8 *bufs[] = {s.d_raw, s.d_a, s.d_b, s.d_bgr, s.d_t, s.d_thresh, s.d_mask, s.d_m0, s.d_m1, s.d_masked};
+    for (u8 *p : bufs)
+        if (p) (void)hipFree(p);
+    if (s.d_mom) (void)hipFree(s.d_mom);
+    if (s.ev_up) (void)hipEventDestroy(s.ev_up);
+    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    s = Slot();
+}
+
+int alloc_slot(imgproc_ctx *c, Slot &s)
+{
+    const size_t px = (size_t)c->cfg.max_width * c->cfg.max_height;
+    HIPCHK(c, hipHostMalloc((void **)&s.h_in, px * 3, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&s.h_mom, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc((void **)&s.d_raw, px * 3));
+    HIPCHK(c, hipMalloc((void **)&s.d_a, px * 3));
+    HIPCHK(c, hipMalloc((void **)&s.d_b, px * 3));
+    HIPCHK(c, hipMalloc((void **)&s.d_bgr, px * 3));
+    HIPCHK(c, hipMalloc((void **)&s.d_t, px * 3));
+    HIPCHK(c, hipMalloc((void **)&s.d_masked, px * 3));
+    HIPCHK(c, hipMalloc((void **)&s.d_thresh, px * IMGPROC_MAX_RANGES));
+    HIPCHK(c, hipMalloc((void **)&s.d_mask, px * IMGPROC_MAX_RANGES));
+    HIPCHK(c, hipMalloc((void **)&s.d_m0, px));
+    HIPCHK(c, hipMalloc((void **)&s.d_m1, px));
+    HIPCHK(c, hipMalloc((void **)&s.d_mom, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES));
+    HIPCHK(c, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    return 0;
+}
+
+// Stage-by-stage chain for one frame whose raw bytes are at d_frame (device).  Final masks land in
+// d_masks_out (n_ranges planes of w*h, tight), moments are ADDED into d_mom (caller zeroes).
+int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, int w, int h, u8 *d_masks_out,
+                unsigned long long *d_mom, int *launches)
+{
+    const Plan &p = c->plan;
+    const size_t t3 = (size_t)w * 3, px = (size_t)w * h;
+    hipStream_t st = c->stream;
+    const u8 *cur = d_frame;
+    size_t cur_stride = row_stride;
+    int bidx = p.pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0;
+    int nl = 0;
+    // buffers: d_bgr = BGR stage, d_a = HSV, d_b = blurred HSV, d_t = temporary (demosaic before pre-blur)
+    if (p.pipe.encoding == IMGPROC_ENC_BAYER_RGGB8) {
+        u8 *dst = p.pipe.pre_blur_k > 1 ? s.d_t : s.d_bgr;
+        HIPCHK(c, ipk::launch_demosaic_rggb(cur, cur_stride, dst, t3, w, h, st));
+        nl++;
+        cur = dst;
+        cur_stride = t3;
+    }
+    if (p.pipe.pre_blur_k > 1) {
+        HIPCHK(c, ipk::launch_gaussian(cur, cur_stride, s.d_bgr, t3, w, h, 3, p.pre, st));
+        nl++;
+        cur = s.d_bgr;
+        cur_stride = t3;
+    }
+    s.bgr_ptr = cur;  // may be the caller's frame itself (then the row stride is the caller's)
+    s.bgr_stride = cur_stride;
+    HIPCHK(c, ipk::launch_bgr2hsv(cur, cur_stride, s.d_a, t3, w, h, bidx, c->d_tables, st));
+    nl++;
+    s.hsv_ptr = s.d_a;
+    const u8 *blur = s.d_a;
+    if (p.pipe.post_blur_k > 1) {
+        HIPCHK(c, ipk::launch_gaussian(s.d_a, t3, s.d_b, t3, w, h, 3, p.post, st));
+        nl++;
+        blur = s.d_b;
+    }
+    s.blur_ptr = blur;
+    const int nr = p.bounds.n;
+    HIPCHK(c, ipk::launch_in_range(blur, t3, s.d_thresh, (size_t)w, px, w, h, p.bounds, st));
+    nl++;
+    for (int r = 0; r < nr; r++) {
+        const u8 *m = s.d_thresh + (size_t)r * px;
+        u8 *final_dst = d_masks_out + (size_t)r * px;
+        for (int i = 0; i < p.pipe.n_morph; i++) {
+            u8 *dst = (i == p.pipe.n_morph - 1) ? final_dst : ((m == s.d_m0) ? s.d_m1 : s.d_m0);
+            HIPCHK(c, ipk::launch_morph(m, (size_t)w, dst, (size_t)w, w, h, p.pipe.morph[i].kind, p.elems[i], st));
+            nl++;
+            m = dst;
+        }
+        if (p.pipe.n_morph == 0) {
+            HIPCHK(c, hipMemcpyAsync(final_dst, m, px, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(c, ipk::launch_moments(final_dst, (size_t)w, w, h, d_mom + 6 * (size_t)r, st));
+        nl++;
+    }
+    if (launches) *launches += nl;
+    return 0;
+}
+
+int check_frame(imgproc_ctx *c, int w, int h, size_t row_stride)
+{
+    if (w < 1 || h < 1) return fail(c, IMGPROC_EINVAL, "frame %dx%d", w, h);
+    if (w > c->cfg.max_width || h > c->cfg.max_height || (size_t)w * h > (size_t)c->cfg.max_width * c->cfg.max_height)
+        return fail(c, IMGPROC_ESIZE, "frame %dx%d exceeds context maximum %dx%d", w, h, c->cfg.max_width, c->cfg.max_height);
+    const size_t need = (size_t)w * (c->plan.pipe.encoding == IMGPROC_ENC_BAYER_RGGB8 ? 1 : 3);
+    if (row_stride < need) return fail(c, IMGPROC_EINVAL, "row stride %zu < %zu", row_stride, need);
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// lifecycle
+// ================================================================================================
+IMGPROC_API int imgproc_version(void) { return IMGPROC_VERSION; }
+
+IMGPROC_API const char *imgproc_strerror(int s)
+{
+    switch (s) {
+    case IMGPROC_OK: return "ok";
+    case IMGPROC_EINVAL: return "invalid argument";
+    case IMGPROC_ENOMEM: return "out of memory";
+    case IMGPROC_EHIP: return "HIP runtime error";
+    case IMGPROC_ESTATE: return "invalid call order / state";
+    case IMGPROC_ESIZE: return "frame exceeds context maximum";
+    case IMGPROC_ENODEV: return "no usable HIP device";
+    case IMGPROC_EUNSUPPORTED: return "unsupported request";
+    default: return "unknown status";
+    }
+}
+
+IMGPROC_API const char *imgproc_last_error(const imgproc_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+IMGPROC_API int imgproc_device_count(int *count)
+{
+    if (!count) return IMGPROC_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *count = 0;
+        return IMGPROC_ENODEV;
+    }
+    *count = n;
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
+{
+    if (!out || !cfg) return IMGPROC_EINVAL;
+    *out = nullptr;
+    if (cfg->max_width < 1 || cfg->max_height < 1 || cfg->n_slots < 1 || cfg->n_slots > 16 || cfg->max_batch < 0)
+        return IMGPROC_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return IMGPROC_ENODEV;
+    if (cfg->device < 0 || cfg->device >= n) return IMGPROC_ENODEV;
+    imgproc_ctx *c = new (std::nothrow) imgproc_ctx();
+    if (!c) return IMGPROC_ENOMEM;
+    c->cfg = *cfg;
+    if (c->cfg.max_batch < 1) c->cfg.max_batch = 1;
+    auto build = [&]() -> int {
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreate(&c->ev_k0));
+        HIPCHK(c, hipEventCreate(&c->ev_k1));
+        // HSV reciprocal tables: cvRound == round-half-even == lrint
+        int tab[512];
+        tab[0] = tab[256] = 0;
+        for (int i = 1; i < 256; i++) {
+            tab[i] = (int)lrint((255 << 12) / (double)i);
+            tab[256 + i] = (int)lrint((180 << 12) / (6.0 * i));
+        }
+        HIPCHK(c, hipMalloc((void **)&c->d_tables, sizeof tab));
+        HIPCHK(c, hipMemcpy(c->d_tables, tab, sizeof tab, hipMemcpyHostToDevice));
+        const size_t px = (size_t)c->cfg.max_width * c->cfg.max_height;
+        HIPCHK(c, hipMalloc((void **)&c->d_s0, px * 3));
+        HIPCHK(c, hipMalloc((void **)&c->d_s1, px * 3));
+        HIPCHK(c, hipMalloc((void **)&c->d_s_mom, sizeof(unsigned long long) * 6));
+        const size_t mb = sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES * (size_t)c->cfg.max_batch;
+        HIPCHK(c, hipMalloc((void **)&c->d_mom_batch, mb));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_mom_batch, mb, hipHostMallocDefault));
+        c->slots.resize(c->cfg.n_slots);
+        for (auto &s : c->slots) {
+            int rc = alloc_slot(c, s);
+            if (rc) return rc;
+        }
+        return 0;
+    };
+    int rc = build();
+    if (rc) {
+        imgproc_destroy(c);
+        return rc;
+    }
+    // default pipeline: the pose_estimate chain (BGR2HSV + inRange, pose_estimate.cpp:203-205), cfg default range
+    imgproc_pipeline p;
+    memset(&p, 0, sizeof p);
+    imgproc_set_pipeline(c, &p);
+    const int32_t lo[1][3] = {{0, 0, 0}}, hi[1][3] = {{256, 256, 256}};
+    imgproc_set_ranges(c, 1, lo, hi);
+    *out = c;
+    return IMGPROC_OK;
+}
+
+IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto &s : c->slots) free_slot(s);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_s0) (void)hipFree(c->d_s0);
+    if (c->d_s1) (void)hipFree(c->d_s1);
+    if (c->d_s_mom) (void)hipFree(c->d_s_mom);
+    if (c->d_mom_batch) (void)hipFree(c->d_mom_batch);
+    if (c->h_mom_batch) (void)hipHostFree(c->h_mom_batch);
+    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+// ================================================================================================
+// configuration
+// ================================================================================================
+static void replan_fused(imgproc_ctx *c)
+{
+    Plan &p = c->plan;
+    p.fused_ok = !p.pipe.force_unfused && !p.pipe.keep_stages &&
+                 ipf::plan_fused(p.pipe, p.elems, p.pre, p.post, p.bounds, &p.fused);
+}
+
+IMGPROC_API int imgproc_set_pipeline(imgproc_ctx *c, const imgproc_pipeline *pp)
+{
+    if (!c || !pp) return IMGPROC_EINVAL;
+    if (pp->encoding < 0 || pp->encoding > IMGPROC_ENC_BAYER_RGGB8) return fail(c, IMGPROC_EINVAL, "encoding %d", pp->encoding);
+    if (pp->n_morph < 0 || pp->n_morph > IMGPROC_MAX_MORPH) return fail(c, IMGPROC_EINVAL, "n_morph %d", pp->n_morph);
+    Plan np;
+    np.pipe = *pp;
+    np.bounds = c->plan.bounds;
+    const int ks[2] = {pp->pre_blur_k, pp->post_blur_k};
+    ipk::Taps *tp[2] = {&np.pre, &np.post};
+    for (int i = 0; i < 2; i++) {
+        int k = ks[i] < 1 ? 1 : ks[i];
+        if (gaussian_taps(k, tp[i]->t)) return fail(c, IMGPROC_EINVAL, "blur ksize %d (odd, <=%d)", ks[i], IMGPROC_MAX_KSIZE);
+        tp[i]->k = k;
+    }
+    np.custom.resize(pp->n_morph);
+    for (int i = 0; i < pp->n_morph; i++) {
+        const imgproc_morph &m = pp->morph[i];
+        if (m.shape < 0 || m.shape > IMGPROC_CUSTOM) return fail(c, IMGPROC_EINVAL, "morph[%d] shape %d", i, m.shape);
+        if (m.shape == IMGPROC_CUSTOM && m.custom && m.kw > 0 && m.kh > 0 && m.kw <= 31 && m.kh <= 31)
+            np.custom[i].assign(m.custom, m.custom + (size_t)m.kw * m.kh);
+        int rc = make_element(m, np.custom[i].empty() ? nullptr : np.custom[i].data(), np.elems[i]);
+        if (rc) return fail(c, rc, "morph[%d]: bad element %dx%d anchor (%d,%d)", i, m.kw, m.kh, m.anchor_x, m.anchor_y);
+        np.pipe.morph[i].custom = np.custom[i].empty() ? nullptr : np.custom[i].data();
+    }
+    c->plan = std::move(np);
+    for (int i = 0; i < c->plan.pipe.n_morph; i++)
+        c->plan.pipe.morph[i].custom = c->plan.custom[i].empty() ? nullptr : c->plan.custom[i].data();
+    replan_fused(c);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_set_ranges(imgproc_ctx *c, int n, const int32_t (*lo)[3], const int32_t (*hi)[3])
+{
+    if (!c || !lo || !hi) return IMGPROC_EINVAL;
+    if (n < 1 || n > IMGPROC_MAX_RANGES) return fail(c, IMGPROC_EINVAL, "n ranges %d (1..%d)", n, IMGPROC_MAX_RANGES);
+    make_bounds(n, lo, hi, c->plan.bounds);
+    replan_fused(c);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_pipeline_is_fused(const imgproc_ctx *c) { return c && c->plan.fused_ok ? 1 : 0; }
+
+// ================================================================================================
+// streaming path
+// ================================================================================================
+IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, size_t stride, int w, int h)
+{
+    if (!c || !data) return IMGPROC_EINVAL;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, IMGPROC_EINVAL, "slot %d", slot);
+    int rc = check_frame(c, w, h, stride);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    Slot &s = c->slots[slot];
+    if (s.in_flight) {  // slot reuse before wait(): finish the old frame first (its result is dropped)
+        HIPCHK(c, hipEventSynchronize(s.ev_done));
+        s.in_flight = false;
+    }
+    const Plan &p = c->plan;
+    const size_t rowb = (size_t)w * (p.pipe.encoding == IMGPROC_ENC_BAYER_RGGB8 ? 1 : 3);
+    if (stride == rowb)
+        memcpy(s.h_in, data, rowb * h);
+    else
+        for (int y = 0; y < h; y++) memcpy(s.h_in + (size_t)y * rowb, data + (size_t)y * stride, rowb);
+    HIPCHK(c, hipMemcpyAsync(s.d_raw, s.h_in, rowb * h, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(s.ev_up, c->copy_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
+    const int nr = p.bounds.n;
+    HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, c->stream));
+    if (p.fused_ok) {
+        HIPCHK(c, ipf::launch_fused(p.fused, s.d_raw, 0, rowb, w, h, 1, s.d_mask, s.d_mom, c->d_tables, c->stream));
+    } else {
+        rc = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr);
+        if (rc) return rc;
+        if (p.pipe.keep_stages)
+            HIPCHK(c, ipk::launch_mask_and(s.bgr_ptr, s.bgr_stride, s.d_mask, (size_t)w, s.d_masked, (size_t)w * 3, w, h, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(s.h_mom, s.d_mom, sizeof(unsigned long long) * 6 * nr, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(s.ev_done, c->stream));
+    s.w = w;
+    s.h = h;
+    s.in_flight = true;
+    s.has_frame = true;
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_wait(imgproc_ctx *c, int slot, imgproc_result *out)
+{
+    if (!c || !out) return IMGPROC_EINVAL;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, IMGPROC_EINVAL, "slot %d", slot);
+    Slot &s = c->slots[slot];
+    if (!s.in_flight) return fail(c, IMGPROC_ESTATE, "wait on slot %d without a submitted frame", slot);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(s.ev_done));
+    s.in_flight = false;
+    memset(out, 0, sizeof *out);
+    out->n_ranges = c->plan.bounds.n;
+    for (int r = 0; r < out->n_ranges; r++) finish_moments(s.h_mom + 6 * r, out->r[r]);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_fetch_stage(imgproc_ctx *c, int slot, int stage, int range, uint8_t *dst, size_t dst_stride)
+{
+    if (!c || !dst) return IMGPROC_EINVAL;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, IMGPROC_EINVAL, "slot %d", slot);
+    Slot &s = c->slots[slot];
+    if (!s.has_frame) return fail(c, IMGPROC_ESTATE, "slot %d holds no frame", slot);
+    if (range < 0 || range >= c->plan.bounds.n) return fail(c, IMGPROC_EINVAL, "range %d", range);
+    const bool keep = c->plan.pipe.keep_stages != 0;
+    if (stage != IMGPROC_STAGE_MASK && !keep)
+        return fail(c, IMGPROC_ESTATE, "stage %d needs pipeline.keep_stages", stage);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (s.in_flight) HIPCHK(c, hipEventSynchronize(s.ev_done));
+    const size_t px = (size_t)s.w * s.h;
+    const u8 *src = nullptr;
+    size_t rowb = 0, src_stride = 0;
+    switch (stage) {
+    case IMGPROC_STAGE_BGR: src = s.bgr_ptr; rowb = (size_t)s.w * 3; src_stride = s.bgr_stride; break;
+    case IMGPROC_STAGE_HSV: src = s.hsv_ptr; rowb = (size_t)s.w * 3; break;
+    case IMGPROC_STAGE_BLUR: src = s.blur_ptr; rowb = (size_t)s.w * 3; break;
+    case IMGPROC_STAGE_THRESH: src = s.d_thresh + px * range; rowb = s.w; break;
+    case IMGPROC_STAGE_MASK: src = s.d_mask + px * range; rowb = s.w; break;
+    case IMGPROC_STAGE_MASKED: src = s.d_masked; rowb = (size_t)s.w * 3; break;
+    default: return fail(c, IMGPROC_EINVAL, "stage %d", stage);
+    }
+    if (!src) return fail(c, IMGPROC_ESTATE, "stage %d was not produced", stage);
+    if (dst_stride < rowb) return fail(c, IMGPROC_EINVAL, "dst stride %zu < %zu", dst_stride, rowb);
+    if (!src_stride) src_stride = rowb;
+    HIPCHK(c, hipMemcpy2D(dst, dst_stride, src, src_stride, rowb, s.h, hipMemcpyDeviceToHost));
+    return IMGPROC_OK;
+}
+
+// ================================================================================================
+// batch paths
+// ================================================================================================
+IMGPROC_API int imgproc_process_batch(imgproc_ctx *c, const uint8_t *frames, size_t frame_stride, size_t row_stride,
+                                      int w, int h, int n, imgproc_result *out)
+{
+    if (!c || !frames || !out || n < 0) return IMGPROC_EINVAL;
+    const int ns = (int)c->slots.size();
+    for (int i = 0; i < n; i++) {
+        const int slot = i % ns;
+        if (i >= ns) {
+            int rc = imgproc_wait(c, slot, &out[i - ns]);
+            if (rc) return rc;
+        }
+        int rc = imgproc_submit(c, slot, frames + (size_t)i * frame_stride, row_stride, w, h);
+        if (rc) return rc;
+    }
+    for (int i = (n > ns ? n - ns : 0); i < n; i++) {
+        int rc = imgproc_wait(c, i % ns, &out[i]);
+        if (rc) return rc;
+    }
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frames, size_t frame_stride,
+                                             size_t row_stride, int w, int h, int n, void *d_masks,
+                                             imgproc_result *out)
+{
+    if (!c || !d_frames || n < 0) return IMGPROC_EINVAL;
+    if (n > c->cfg.max_batch) return fail(c, IMGPROC_ESIZE, "batch %d > max_batch %d", n, c->cfg.max_batch);
+    if (n == 0) return IMGPROC_OK;
+    int rc = check_frame(c, w, h, row_stride);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const Plan &p = c->plan;
+    const int nr = p.bounds.n;
+    const size_t px = (size_t)w * h;
+    const size_t mom_bytes = sizeof(unsigned long long) * 6 * nr * (size_t)n;
+    Slot &s = c->slots[0];
+    if (s.in_flight) {
+        HIPCHK(c, hipEventSynchronize(s.ev_done));
+        s.in_flight = false;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_mom_batch, 0, mom_bytes, c->stream));
+    c->prof_valid = false;
+    c->prof_launches = 0;
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_k0, c->stream));
+    if (p.fused_ok) {
+        HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks,
+                                    c->d_mom_batch, c->d_tables, c->stream));
+        c->prof_launches = 1;
+    } else {
+        for (int i = 0; i < n; i++) {
+            u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;
+            rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)i * frame_stride, row_stride, w, h, mout,
+                             c->d_mom_batch + (size_t)i * nr * 6, &c->prof_launches);
+            if (rc) return rc;
+        }
+    }
+    if (c->profiling) {
+        HIPCHK(c, hipEventRecord(c->ev_k1, c->stream));
+        c->prof_valid = true;
+    }
+    if (out) {
+        HIPCHK(c, hipMemcpyAsync(c->h_mom_batch, c->d_mom_batch, mom_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n; i++) {
+            memset(&out[i], 0, sizeof out[i]);
+            out[i].n_ranges = nr;
+            for (int r = 0; r < nr; r++) finish_moments(c->h_mom_batch + ((size_t)i * nr + r) * 6, out[i].r[r]);
+        }
+    }
+    return IMGPROC_OK;
+}
+
+// ================================================================================================
+// single stages on host buffers
+// ================================================================================================
+namespace {
+int stage_io_check(imgproc_ctx *c, const void *src, void *dst, int w, int h, size_t sstride, size_t dstride,
+                   size_t srow, size_t drow)
+{
+    if (!c || !src || !dst) return IMGPROC_EINVAL;
+    if (w < 1 || h < 1) return fail(c, IMGPROC_EINVAL, "frame %dx%d", w, h);
+    if ((size_t)w * h > (size_t)c->cfg.max_width * c->cfg.max_height)
+        return fail(c, IMGPROC_ESIZE, "frame %dx%d exceeds context maximum", w, h);
+    if (sstride < srow || dstride < drow) return fail(c, IMGPROC_EINVAL, "stride too small");
+    return 0;
+}
+}  // namespace
+
+#define UPLOAD(c, dptr, hptr, hstride, rowb, h) \
+    HIPCHK(c, hipMemcpy2DAsync(dptr, rowb, hptr, hstride, rowb, h, hipMemcpyHostToDevice, (c)->stream))
+#define DOWNLOAD(c, hptr, hstride, dptr, rowb, h)                                                           \
+    do {                                                                                                    \
+        HIPCHK(c, hipMemcpy2DAsync(hptr, hstride, dptr, rowb, rowb, h, hipMemcpyDeviceToHost, (c)->stream)); \
+        HIPCHK(c, hipStreamSynchronize((c)->stream));                                                       \
+    } while (0)
+
+IMGPROC_API int imgproc_cvt_bgr2hsv(imgproc_ctx *c, const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride,
+                                    int w, int h, int encoding)
+{
+    const size_t rowb = (size_t)w * 3;
+    int rc = stage_io_check(c, src, dst, w, h, sstride, dstride, rowb, rowb);
+    if (rc) return rc;
+    if (encoding != IMGPROC_ENC_BGR8 && encoding != IMGPROC_ENC_RGB8) return fail(c, IMGPROC_EINVAL, "encoding %d", encoding);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    UPLOAD(c, c->d_s0, src, sstride, rowb, h);
+    HIPCHK(c, ipk::launch_bgr2hsv(c->d_s0, rowb, c->d_s1, rowb, w, h, encoding == IMGPROC_ENC_RGB8 ? 2 : 0, c->d_tables, c->stream));
+    DOWNLOAD(c, dst, dstride, c->d_s1, rowb, h);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_gaussian_blur(imgproc_ctx *c, const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride,
+                                      int w, int h, int channels, int ksize)
+{
+    if (channels != 1 && channels != 3) return c ? fail(c, IMGPROC_EINVAL, "channels %d", channels) : IMGPROC_EINVAL;
+    const size_t rowb = (size_t)w * channels;
+    int rc = stage_io_check(c, src, dst, w, h, sstride, dstride, rowb, rowb);
+    if (rc) return rc;
+    ipk::Taps t;
+    t.k = ksize < 1 ? 1 : ksize;
+    if (gaussian_taps(t.k, t.t)) return fail(c, IMGPROC_EINVAL, "ksize %d (odd, <=%d)", ksize, IMGPROC_MAX_KSIZE);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    UPLOAD(c, c->d_s0, src, sstride, rowb, h);
+    HIPCHK(c, ipk::launch_gaussian(c->d_s0, rowb, c->d_s1, rowb, w, h, channels, t, c->stream));
+    DOWNLOAD(c, dst, dstride, c->d_s1, rowb, h);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_in_range(imgproc_ctx *c, const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride,
+                                 int w, int h, const int32_t lo[3], const int32_t hi[3])
+{
+    if (!lo || !hi) return IMGPROC_EINVAL;
+    const size_t rowb = (size_t)w * 3;
+    int rc = stage_io_check(c, src, dst, w, h, sstride, dstride, rowb, (size_t)w);
+    if (rc) return rc;
+    ipk::Bounds b;
+    make_bounds(1, reinterpret_cast<const int32_t(*)[3]>(lo), reinterpret_cast<const int32_t(*)[3]>(hi), b);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    UPLOAD(c, c->d_s0, src, sstride, rowb, h);
+    HIPCHK(c, ipk::launch_in_range(c->d_s0, rowb, c->d_s1, (size_t)w, (size_t)w * h, w, h, b, c->stream));
+    DOWNLOAD(c, dst, dstride, c->d_s1, (size_t)w, h);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_morphology(imgproc_ctx *c, const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride,
+                                   int w, int h, const imgproc_morph *op)
+{
+    if (!op) return IMGPROC_EINVAL;
+    int rc = stage_io_check(c, src, dst, w, h, sstride, dstride, (size_t)w, (size_t)w);
+    if (rc) return rc;
+    ipk::Element e;
+    if (op->shape < 0 || op->shape > IMGPROC_CUSTOM) return fail(c, IMGPROC_EINVAL, "shape %d", op->shape);
+    rc = make_element(*op, op->custom, e);
+    if (rc) return fail(c, rc, "bad element %dx%d anchor (%d,%d)", op->kw, op->kh, op->anchor_x, op->anchor_y);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    UPLOAD(c, c->d_s0, src, sstride, (size_t)w, h);
+    HIPCHK(c, ipk::launch_morph(c->d_s0, (size_t)w, c->d_s1, (size_t)w, w, h, op->kind, e, c->stream));
+    DOWNLOAD(c, dst, dstride, c->d_s1, (size_t)w, h);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_mask_moments(imgproc_ctx *c, const uint8_t *mask, size_t stride, int w, int h, imgproc_moments *out)
+{
+    int rc = stage_io_check(c, mask, out, w, h, stride, (size_t)w, (size_t)w, (size_t)w);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    UPLOAD(c, c->d_s0, mask, stride, (size_t)w, h);
+    HIPCHK(c, hipMemsetAsync(c->d_s_mom, 0, sizeof(unsigned long long) * 6, c->stream));
+    HIPCHK(c, ipk::launch_moments(c->d_s0, (size_t)w, w, h, c->d_s_mom, c->stream));
+    unsigned long long m[6];
+    HIPCHK(c, hipMemcpyAsync(m, c->d_s_mom, sizeof m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    finish_moments(m, *out);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_demosaic_rggb(imgproc_ctx *c, const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride,
+                                      int w, int h)
+{
+    int rc = stage_io_check(c, src, dst, w, h, sstride, dstride, (size_t)w, (size_t)w * 3);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    UPLOAD(c, c->d_s0, src, sstride, (size_t)w, h);
+    HIPCHK(c, ipk::launch_demosaic_rggb(c->d_s0, (size_t)w, c->d_s1, (size_t)w * 3, w, h, c->stream));
+    DOWNLOAD(c, dst, dstride, c->d_s1, (size_t)w * 3, h);
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_mask_and(imgproc_ctx *c, const uint8_t *bgr, size_t sstride, const uint8_t *mask, size_t mstride,
+                                 uint8_t *dst, size_t dstride, int w, int h)
+{
+    if (!mask) return IMGPROC_EINVAL;
+    const size_t rowb = (size_t)w * 3;
+    int rc = stage_io_check(c, bgr, dst, w, h, sstride, dstride, rowb, rowb);
+    if (rc) return rc;
+    if (mstride < (size_t)w) return fail(c, IMGPROC_EINVAL, "mask stride too small");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    Slot &s = c->slots[0];
+    if (s.in_flight) {
+        HIPCHK(c, hipEventSynchronize(s.ev_done));
+        s.in_flight = false;
+    }
+    UPLOAD(c, c->d_s0, bgr, sstride, rowb, h);
+    UPLOAD(c, s.d_m0, mask, mstride, (size_t)w, h);
+    HIPCHK(c, ipk::launch_mask_and(c->d_s0, rowb, s.d_m0, (size_t)w, c->d_s1, rowb, w, h, c->stream));
+    DOWNLOAD(c, dst, dstride, c->d_s1, rowb, h);
+    return IMGPROC_OK;
+}
+
+// getStructuringElement (objectPolygonPath.cpp:31-32).  Host only.
+IMGPROC_API int imgproc_structuring_element(int shape, int kw, int kh, uint8_t *elem)
+{
+    if (!elem || kw < 1 || kh < 1 || kw > IMGPROC_MAX_KSIZE || kh > IMGPROC_MAX_KSIZE) return IMGPROC_EINVAL;
+    if (shape != IMGPROC_RECT && shape != IMGPROC_CROSS && shape != IMGPROC_ELLIPSE) return IMGPROC_EINVAL;
+    const int cy = kh / 2, cx = kw / 2;
+    memset(elem, 0, (size_t)kw * kh);
+    for (int row = 0; row < kh; row++) {
+        int from = 0, to = 0;  // [from, to)
+        if (shape == IMGPROC_RECT) {
+            to = kw;
+        } else if (shape == IMGPROC_CROSS) {
+            if (row == cy) to = kw;
+            else { from = cx; to = cx + 1; }
+        } else {
+            const int dy = row - cy;
+            if (cy == 0) {
+                // degenerate one-row ellipse: OpenCV's inv_r2 = 0 -> half width 0
+                from = cx; to = cx + 1;
+            } else {
+                const double half = cx * std::sqrt((double)(cy * cy - dy * dy) / ((double)cy * cy));
+                const int dx = (int)lrint(half);
+                from = cx - dx < 0 ? 0 : cx - dx;
+                to = cx + dx + 1 > kw ? kw : cx + dx + 1;
+            }
+        }
+        for (int i = from; i < to; i++) elem[(size_t)row * kw + i] = 1;
+    }
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_gaussian_taps(int ksize, int32_t *taps)
+{
+    if (!taps) return IMGPROC_EINVAL;
+    int t[31];
+    int rc = gaussian_taps(ksize, t);
+    if (rc) return rc;
+    for (int i = 0; i < ksize; i++) taps[i] = t[i];
+    return IMGPROC_OK;
+}
+
+// ================================================================================================
+// device memory helpers / measurement
+// ================================================================================================
+IMGPROC_API int imgproc_dev_alloc(imgproc_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return IMGPROC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMalloc(dptr, bytes));
+    return IMGPROC_OK;
+}
+IMGPROC_API int imgproc_dev_free(imgproc_ctx *c, void *dptr)
+{
+    if (!c) return IMGPROC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipFree(dptr));
+    return IMGPROC_OK;
+}
+IMGPROC_API int imgproc_dev_upload(imgproc_ctx *c, void *dptr, const void *src, size_t bytes)
+{
+    if (!c || !dptr || !src) return IMGPROC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+    return IMGPROC_OK;
+}
+IMGPROC_API int imgproc_dev_download(imgproc_ctx *c, void *dst, const void *dptr, size_t bytes)
+{
+    if (!c || !dptr || !dst) return IMGPROC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost));
+    return IMGPROC_OK;
+}
+IMGPROC_API int imgproc_set_profiling(imgproc_ctx *c, int on)
+{
+    if (!c) return IMGPROC_EINVAL;
+    c->profiling = on != 0;
+    c->prof_valid = false;
+    return IMGPROC_OK;
+}
+IMGPROC_API int imgproc_last_kernel_ms(imgproc_ctx *c, float *ms, int *launches)
+{
+    if (!c || !ms) return IMGPROC_EINVAL;
+    if (!c->prof_valid) return fail(c, IMGPROC_ESTATE, "no profiled batch call yet");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(c->ev_k1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev_k0, c->ev_k1));
+    if (launches) *launches = c->prof_launches;
+    return IMGPROC_OK;
+}
+IMGPROC_API int imgproc_synchronize(imgproc_ctx *c)
+{
+    if (!c) return IMGPROC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IMGPROC_OK;
+}

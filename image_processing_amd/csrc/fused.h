@@ -1,0 +1,29 @@
+// Fused chain kernel (fused.hip): BGR/RGB -> HSV -> Gaussian -> inRange -> morphology -> mask + moments
+// in one launch over a whole batch, for the pipelines plan_fused() accepts.
+#pragma once
+#include "../../include/imgproc.h"
+#include "kernels.h"
+
+namespace ipf {
+
+struct FusedPlan {
+    int variant;      // kernel specialisation chosen by plan_fused
+    int bidx;         // 0 BGR input, 2 RGB input
+    int post_k;       // post-HSV blur ksize (1 = none)
+    int n_groups;     // merged morphology groups
+    int kind[8];      // per group: 0 erode, 1 dilate
+    int lo_x[8], hi_x[8], lo_y[8], hi_y[8];  // per group: window offset range [lo, hi] (rect, merged)
+    ipk::Bounds bounds;
+};
+
+// true when the pipeline can run fused; fills *out
+bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const ipk::Taps &pre, const ipk::Taps &post,
+                const ipk::Bounds &bounds, FusedPlan *out);
+
+// frames: n frames at d_frames + i*frame_stride; masks (may be null): [n][n_ranges][h][w]; moments added into
+// d_mom[n][n_ranges][6] (caller zeroes)
+hipError_t launch_fused(const FusedPlan &plan, const ipk::u8 *d_frames, size_t frame_stride, size_t row_stride, int w,
+                        int h, int n, ipk::u8 *d_masks, unsigned long long *d_mom, const int *d_tables,
+                        hipStream_t stream);
+
+}  // namespace ipf

@@ -1,0 +1,205 @@
+"""GPU parity of the whole chain through the C ABI (submit/wait, fetch_stage, batch paths) against the
+oracle's chain on the same seeded synthetic frames; fused == unfused == oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import image_processing_amd as ip
+from image_processing_amd import _lib as L
+from image_processing_amd.synth import DEFAULT_RANGE, synth_batch, synth_bayer_rggb, synth_frame
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("m00", "m10", "m01", "m20", "m11", "m02")
+
+
+def morph_tuples(ops):
+    return [(m.kind, m.shape, m.kw, m.kh, m.anchor[0], m.anchor[1]) for m in ops]
+
+
+PRESETS = {
+    "pose_estimate": dict(pre_blur_k=0, post_blur_k=0, morph=[]),  # pose_estimate.cpp:203-205
+    "pose_estimate_full": dict(pre_blur_k=0, post_blur_k=5, morph=ip.MORPH_POSE_ESTIMATE),  # with :204,:206 enabled
+    "baseline": dict(pre_blur_k=0, post_blur_k=5, morph=ip.MORPH_BASELINE),
+    "polygon_path": dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH),  # objectPolygonPath.cpp:182-188
+    "c1": dict(pre_blur_k=0, post_blur_k=0, morph=ip.MORPH_BASELINE),  # BASELINE config 1
+}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    with ip.ImgProc(1920, 1200, n_slots=2, max_batch=8) as g:
+        yield g
+
+
+def check_moments(res, exp):
+    assert [res[k] for k in KEYS] == [int(v) for v in exp]
+    if exp[0]:
+        assert abs(res["cx"] - float(exp[1]) / float(exp[0])) <= 1e-9 * max(1.0, abs(res["cx"]))
+        assert abs(res["cy"] - float(exp[2]) / float(exp[0])) <= 1e-9 * max(1.0, abs(res["cy"]))
+        assert res["found"] == 1
+    else:
+        assert res["found"] == 0 and res["cx"] == -1.0
+
+
+@pytest.mark.parametrize("name", list(PRESETS))
+@pytest.mark.parametrize("hw", [(64, 96), (123, 517), (480, 640)])
+def test_stages_unfused(gpu, oracle, name, hw):
+    p = PRESETS[name]
+    f = synth_frame(hw[1], hw[0], 5)
+    ranges = [DEFAULT_RANGE, ((0, 0, 0), (90, 256, 256))]
+    gpu.set_pipeline(keep_stages=True, **p)
+    gpu.set_ranges(ranges)
+    assert not gpu.is_fused
+    res = gpu.process(f, slot=1)
+    exp = oracle.chain(f, pre_blur_k=p["pre_blur_k"], post_blur_k=p["post_blur_k"], morph=morph_tuples(p["morph"]),
+                       ranges=ranges)
+    assert (gpu.fetch_stage(1, L.STAGE_BGR) == exp["bgr"]).all()
+    assert (gpu.fetch_stage(1, L.STAGE_HSV) == exp["hsv"]).all()
+    assert (gpu.fetch_stage(1, L.STAGE_BLUR) == exp["blur"]).all()
+    for r in range(2):
+        assert (gpu.fetch_stage(1, L.STAGE_THRESH, r) == exp["thresh"][r]).all()
+        assert (gpu.fetch_stage(1, L.STAGE_MASK, r) == exp["mask"][r]).all()
+        check_moments(res[r], exp["moments"][r])
+    assert (gpu.fetch_stage(1, L.STAGE_MASKED) == oracle.mask_and(exp["bgr"], exp["mask"][0])).all()
+    assert exp["moments"][0][0] > 0  # the scene really contains the marker
+
+
+@pytest.mark.parametrize("name", list(PRESETS))
+@pytest.mark.parametrize("hw", [(1, 1), (5, 3), (17, 13), (64, 96), (100, 250), (123, 517), (480, 640), (1200, 1920)])
+@pytest.mark.parametrize("rgb", [False, True])
+def test_chain_default_path(gpu, oracle, name, hw, rgb):
+    """Whatever plan the library picks (fused when available) must equal the oracle."""
+    if hw == (1200, 1920) and (rgb or name not in ("baseline", "polygon_path")):
+        pytest.skip("full size once per headline preset")
+    p = PRESETS[name]
+    f = synth_frame(hw[1], hw[0], 11, rgb=rgb)
+    gpu.set_pipeline(encoding=L.ENC_RGB8 if rgb else L.ENC_BGR8, **p)
+    gpu.set_ranges([DEFAULT_RANGE])
+    res = gpu.process(f)
+    exp = oracle.chain(f, encoding=1 if rgb else 0, pre_blur_k=p["pre_blur_k"], post_blur_k=p["post_blur_k"],
+                       morph=morph_tuples(p["morph"]), ranges=[DEFAULT_RANGE], stages=False)
+    assert (gpu.fetch_stage(0, L.STAGE_MASK) == exp["mask"][0]).all()
+    check_moments(res[0], exp["moments"][0])
+
+
+@pytest.mark.parametrize("name", ["baseline", "polygon_path", "pose_estimate"])
+def test_fused_equals_unfused(gpu, name):
+    p = PRESETS[name]
+    frames = synth_batch(517, 123, 3)
+    outs = []
+    for force in (False, True):
+        gpu.set_pipeline(force_unfused=force, **p)
+        gpu.set_ranges([DEFAULT_RANGE])
+        r = []
+        for f in frames:
+            res = gpu.process(f)
+            r.append((gpu.fetch_stage(0, L.STAGE_MASK), [res[0][k] for k in KEYS]))
+        outs.append(r)
+    for (m0, k0), (m1, k1) in zip(*outs):
+        assert (m0 == m1).all() and k0 == k1
+
+
+def test_edge_masks(gpu, oracle):
+    gpu.set_pipeline(**PRESETS["baseline"])
+    for val, rng in ((0, DEFAULT_RANGE), (255, ((0, 0, 0), (256, 256, 256))), (255, ((256, 0, 0), (0, 256, 256)))):
+        f = np.full((37, 61, 3), val, np.uint8)
+        gpu.set_ranges([rng])
+        res = gpu.process(f)
+        exp = oracle.chain(f, post_blur_k=5, morph=morph_tuples(ip.MORPH_BASELINE), ranges=[rng], stages=False)
+        assert (gpu.fetch_stage(0, L.STAGE_MASK) == exp["mask"][0]).all()
+        check_moments(res[0], exp["moments"][0])
+
+
+def test_bayer_chain(gpu, oracle):
+    raw = synth_bayer_rggb(250, 100, 2)
+    gpu.set_pipeline(encoding=L.ENC_BAYER_RGGB8, post_blur_k=5, morph=ip.MORPH_BASELINE)
+    gpu.set_ranges([DEFAULT_RANGE])
+    res = gpu.process(raw)
+    exp = oracle.chain(raw, encoding=2, post_blur_k=5, morph=morph_tuples(ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE],
+                       stages=False)
+    assert (gpu.fetch_stage(0, L.STAGE_MASK) == exp["mask"][0]).all()
+    check_moments(res[0], exp["moments"][0])
+
+
+def test_stress_pipeline_small(gpu, oracle):
+    """BASELINE config 5's operators (15x15 Gaussian, 9x9 ellipse, 8 ranges) at a size the oracle finishes fast."""
+    bands = [(20 * i, 20 * i + 19) for i in range(8)]
+    f = synth_frame(320, 180, 4, hue_bands=bands)
+    ranges = [((lo, 100, 80), (hi, 255, 255)) for lo, hi in bands]
+    morph = [ip.E(9, L.ELLIPSE), ip.D(9, L.ELLIPSE)]
+    gpu.set_pipeline(post_blur_k=15, morph=morph)
+    gpu.set_ranges(ranges)
+    res = gpu.process(f)
+    exp = oracle.chain(f, post_blur_k=15, morph=morph_tuples(morph), ranges=ranges, stages=False)
+    for r in range(8):
+        assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all()
+        check_moments(res[r], exp["moments"][r])
+    assert sum(int(exp["moments"][r][0] > 0) for r in range(8)) >= 4
+
+
+def test_process_batch_host(gpu, oracle):
+    frames = synth_batch(160, 120, 7)
+    p = PRESETS["baseline"]
+    gpu.set_pipeline(**p)
+    gpu.set_ranges([DEFAULT_RANGE])
+    res = gpu.process_batch(frames)
+    assert len(res) == 7
+    for f, r in zip(frames, res):
+        exp = oracle.chain(f, post_blur_k=5, morph=morph_tuples(p["morph"]), ranges=[DEFAULT_RANGE], stages=False)
+        check_moments(r[0], exp["moments"][0])
+
+
+@pytest.mark.parametrize("name", ["baseline", "polygon_path"])
+@pytest.mark.parametrize("force_unfused", [False, True])
+def test_process_batch_device(gpu, oracle, name, force_unfused):
+    p = PRESETS[name]
+    w, h, n = 640, 480, 5
+    frames = synth_batch(w, h, n)
+    ranges = [DEFAULT_RANGE, ((0, 0, 0), (60, 256, 256))]
+    gpu.set_pipeline(force_unfused=force_unfused, **p)
+    gpu.set_ranges(ranges)
+    d_in = gpu.dev_alloc(frames.nbytes)
+    d_out = gpu.dev_alloc(n * 2 * w * h)
+    try:
+        gpu.dev_upload(d_in, frames)
+        res = gpu.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, d_out)
+        masks = gpu.dev_download(d_out, (n, 2, h, w))
+        for i in range(n):
+            exp = oracle.chain(frames[i], pre_blur_k=p["pre_blur_k"], post_blur_k=p["post_blur_k"],
+                               morph=morph_tuples(p["morph"]), ranges=ranges, stages=False)
+            for r in range(2):
+                assert (masks[i, r] == exp["mask"][r]).all()
+                check_moments(res[i][r], exp["moments"][r])
+        # no mask output requested: moments only
+        res2 = gpu.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, None)
+        assert [[m[k] for k in KEYS] for fr in res2 for m in fr] == [[m[k] for k in KEYS] for fr in res for m in fr]
+    finally:
+        gpu.dev_free(d_in)
+        gpu.dev_free(d_out)
+
+
+def test_full_size_properties(gpu, oracle):
+    """BASELINE config 2 size (1920x1200): size-independent properties on a batch + oracle on one frame."""
+    w, h, n = 1920, 1200, 8
+    frames = synth_batch(w, h, n, unique=2)
+    gpu.set_pipeline(**PRESETS["baseline"])
+    gpu.set_ranges([DEFAULT_RANGE])
+    d_in = gpu.dev_alloc(frames.nbytes)
+    d_out = gpu.dev_alloc(n * w * h)
+    try:
+        gpu.dev_upload(d_in, frames)
+        res = gpu.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, d_out)
+        masks = gpu.dev_download(d_out, (n, 1, h, w))
+        assert set(np.unique(masks)) <= {0, 255}
+        for i in range(n):
+            ys, xs = np.nonzero(masks[i, 0])
+            assert res[i][0]["m00"] == len(xs) and res[i][0]["m10"] == int(xs.sum()) and res[i][0]["m01"] == int(ys.sum())
+        # frame i+2 is frame i rolled down by one row (synth_batch): away from the wrap rows the masks shift with it
+        assert (masks[2, 0][8:-8] == masks[0, 0][7:-9]).all()
+        exp = oracle.chain(frames[1], post_blur_k=5, morph=morph_tuples(ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE],
+                           stages=False)
+        assert (masks[1, 0] == exp["mask"][0]).all()
+        check_moments(res[1][0], exp["moments"][0])
+    finally:
+        gpu.dev_free(d_in)
+        gpu.dev_free(d_out)

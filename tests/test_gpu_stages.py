@@ -1,0 +1,140 @@
+"""GPU parity, stage by stage: every cv:: call on the reference's path, through the C ABI, against the
+oracle on the same seeded inputs.  Bar: bit-exact (u8 / integer work)."""
+import numpy as np
+import pytest
+
+import image_processing_amd as ip
+from image_processing_amd import _lib as L
+from image_processing_amd.synth import synth_bayer_rggb, synth_frame
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 1), (1, 13), (13, 1), (17, 13), (16, 64), (37, 250), (64, 256), (123, 517), (480, 640)]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    with ip.ImgProc(1920, 1200, n_slots=2, max_batch=4) as g:
+        yield g
+
+
+@pytest.mark.parametrize("hw", SHAPES)
+def test_bgr2hsv(gpu, oracle, hw):
+    img = np.random.default_rng(hw[0] * 1000 + hw[1]).integers(0, 256, hw + (3,), dtype=np.uint8)
+    assert (gpu.cvtColor_BGR2HSV(img) == oracle.bgr2hsv(img)).all()
+    assert (gpu.cvtColor_BGR2HSV(img, rgb=True) == oracle.bgr2hsv(img, rgb=True)).all()
+
+
+def test_bgr2hsv_all_colours_lattice(gpu, oracle, kat):
+    g = np.arange(0, 256, 3, dtype=np.uint8)
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(86, -1, 3)
+    assert (gpu.cvtColor_BGR2HSV(lat) == oracle.bgr2hsv(lat)).all()
+    src = np.array([[p for p, _ in kat["bgr2hsv"]]], np.uint8)
+    exp = np.array([[q for _, q in kat["bgr2hsv"]]], np.uint8)
+    assert (gpu.cvtColor_BGR2HSV(src) == exp).all()
+
+
+@pytest.mark.parametrize("hw", SHAPES)
+@pytest.mark.parametrize("k", [3, 5, 7, 15])
+def test_gaussian(gpu, oracle, hw, k):
+    rng = np.random.default_rng(hw[0] * 31 + hw[1] + k)
+    img3 = rng.integers(0, 256, hw + (3,), dtype=np.uint8)
+    assert (gpu.GaussianBlur(img3, k) == oracle.gaussian_blur(img3, k)).all()
+    img1 = rng.integers(0, 256, hw, dtype=np.uint8)
+    assert (gpu.GaussianBlur(img1, k) == oracle.gaussian_blur(img1, k)).all()
+
+
+def test_gaussian_kats(gpu, kat):
+    img = np.zeros((21, 21), np.uint8)
+    img[10, 1] = 255
+    out = gpu.GaussianBlur(img, 5)
+    assert out[10, 0] == 48 and out[10, 1] == 42  # reflect-101 traps of SURVEY §A.8
+    img[:] = 0
+    img[10, 10] = 255
+    out = gpu.GaussianBlur(img, 5)
+    assert out[10, 10] == 36 and out[10, 11] == 24 and out[11, 11] == 16 and out[12, 12] == 1
+
+
+@pytest.mark.parametrize("hw", SHAPES)
+def test_in_range(gpu, oracle, hw):
+    img = np.random.default_rng(hw[0] + 7 * hw[1]).integers(0, 256, hw + (3,), dtype=np.uint8)
+    for lo, hi in [((0, 0, 0), (256, 256, 256)), ((100, 120, 80), (130, 255, 255)), ((256, 0, 0), (0, 256, 256)),
+                   ((10, 20, 30), (200, 220, 230)), ((-5, 0, 0), (300, 255, 255)), ((0, 0, 0), (-1, 255, 255)),
+                   ((128, 128, 128), (128, 128, 128))]:
+        assert (gpu.inRange(img, lo, hi) == oracle.in_range(img, lo, hi)).all()
+
+
+@pytest.mark.parametrize("hw", SHAPES)
+def test_morphology(gpu, oracle, hw):
+    rng = np.random.default_rng(hw[0] * 3 + hw[1])
+    binm = np.where(rng.random(hw) < 0.6, 255, 0).astype(np.uint8)
+    gray = rng.integers(0, 256, hw, dtype=np.uint8)
+    ops = [(L.RECT, 3, 3), (L.RECT, 8, 8), (L.ELLIPSE, 9, 9), (L.CROSS, 5, 5), (L.RECT, 2, 5), (L.ELLIPSE, 15, 15),
+           (L.RECT, 31, 31)]
+    for img in (binm, gray):
+        for shape, kw, kh in ops:
+            e = oracle.structuring_element(shape, kw, kh)
+            for kind in (L.ERODE, L.DILATE):
+                got = gpu.morphology(img, ip.MorphOp(kind, shape, kw, kh))
+                assert (got == oracle.morph(img, kind, e)).all(), (shape, kw, kh, kind)
+    e = (rng.random((7, 5)) < 0.5).astype(np.uint8)
+    e[3, 2] = 1
+    for kind in (L.ERODE, L.DILATE):
+        got = gpu.morphology(gray, ip.MorphOp(kind, L.CUSTOM, 5, 7, (1, 6), e))
+        assert (got == oracle.morph(gray, kind, e, (1, 6))).all()
+
+
+def test_morph_kats(gpu):
+    img = np.zeros((40, 40), np.uint8)
+    img[20, 17] = 255
+    ys, xs = np.nonzero(gpu.dilate(img, 8))
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (14, 21, 17, 24)
+    assert (gpu.erode(np.full((7, 9), 255, np.uint8), 3) == 255).all()
+
+
+@pytest.mark.parametrize("hw", SHAPES + [(1200, 1920)])
+def test_moments(gpu, oracle, hw):
+    img = np.where(np.random.default_rng(hw[0] ^ hw[1]).random(hw) < 0.4, 255, 0).astype(np.uint8)
+    img[0, 0] = 7  # non-binary nonzero counts as set
+    m = gpu.moments(img)
+    exp = oracle.moments(img)
+    assert [m[k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")] == exp.tolist()
+    assert m["cx"] == float(exp[1]) / float(exp[0]) and m["cy"] == float(exp[2]) / float(exp[0])
+    z = gpu.moments(np.zeros(hw, np.uint8))
+    assert z["found"] == 0 and z["cx"] == -1.0 and z["m00"] == 0
+
+
+@pytest.mark.parametrize("hw", [(8, 10), (9, 11), (3, 3), (2, 9), (16, 3), (1, 1), (61, 127), (480, 640)])
+def test_demosaic(gpu, oracle, hw):
+    raw = np.random.default_rng(hw[0] + hw[1]).integers(0, 256, hw, dtype=np.uint8)
+    assert (gpu.demosaic_rggb(raw) == oracle.bayer_rggb2bgr(raw)).all()
+
+
+def test_mask_and(gpu, oracle):
+    f = synth_frame(250, 37, 1)
+    m = np.where(np.random.default_rng(0).random((37, 250)) < 0.5, 255, 0).astype(np.uint8)
+    assert (gpu.mask_and(f, m) == oracle.mask_and(f, m)).all()
+
+
+def test_strided_input(gpu, oracle):
+    big = np.random.default_rng(9).integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    view = big[5:42, 3:64]  # row stride 210, not contiguous, odd offsets
+    lib = L.load()
+    out = np.empty((37, 61, 3), np.uint8)
+    rc = lib.imgproc_cvt_bgr2hsv(gpu._ctx, view.ctypes.data, view.strides[0], out.ctypes.data, out.strides[0], 61, 37, 0)
+    assert rc == 0
+    assert (out == oracle.bgr2hsv(np.ascontiguousarray(view))).all()
+
+
+def test_errors(gpu):
+    with pytest.raises(ip.ImgProcError) as e:
+        gpu.GaussianBlur(np.zeros((4, 4), np.uint8), 4)
+    assert e.value.status == L.EINVAL
+    with pytest.raises(ip.ImgProcError) as e:
+        gpu.cvtColor_BGR2HSV(np.zeros((1300, 2000, 3), np.uint8))
+    assert e.value.status == L.ESIZE
+    with pytest.raises(ip.ImgProcError) as e:
+        gpu.wait(1)
+    assert e.value.status == L.ESTATE
+    with pytest.raises(ip.ImgProcError):
+        gpu.morphology(np.zeros((4, 4), np.uint8), ip.MorphOp(L.ERODE, L.RECT, 40, 3))
