@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): frames/s of the full fused chain (5x5 Gaussian on HSV, HSV inRange,
+3x3 erode + dilate, moments) on 1920x1200 BGR8 frames, a device-resident batch of 256 frames per GPU per
+step, plus the achieved HBM GB/s of the chain kernel against the MI355X roofline and the CPU port of
+the same chain timed on the host's cores.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One process per GPU; frames are sharded across ranks with NO data-path collective (the path has no
+cross-frame step), so scaling is weak: every rank processes its own 256-frame batch per step.  The only
+inter-rank traffic is the timing barrier / max-reduction (control plane, gloo).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, BATCH = 1920, 1200, 256
+ALGO_BYTES_PER_FRAME = W * H * 4  # 3 B/px read + 1 B/px mask written
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(frames: np.ndarray, n_frames: int, threads: int) -> dict:
+    """Times the CPU port (oracle/cpu_ref.c built -O3) of the same chain on a bounded sample."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import image_processing_amd as ip
+    from image_processing_amd.synth import DEFAULT_RANGE
+    from oracle import Oracle
+
+    orc = Oracle(fast=True)
+    morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in ip.MORPH_BASELINE]
+
+    def one(i):
+        return orc.chain(frames[i % len(frames)], post_blur_k=5, morph=morph, ranges=[DEFAULT_RANGE], stages=False)["moments"]
+
+    one(0)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
+        list(ex.map(one, range(n_frames)))
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n_frames} frames of {W}x{H} BGR8, same chain, oracle/cpu_ref.c -O3 x86-64-v3, "
+                      f"{threads} threads (one frame per thread at a time); OpenCV itself is absent from the image"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")
+    ap.add_argument("--check", action="store_true", help="also verify one frame of the batch against the oracle")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import image_processing_amd as ip
+    from image_processing_amd.synth import DEFAULT_RANGE, synth_batch
+
+    # synthetic frames: 8 unique seeded frames per rank, replicated (rolled) to 256 distinct HBM buffers
+    uniq = 8
+    base_np = synth_batch(W, H, uniq, seed=0x1A6E5EED + 1000 * rank)
+    base = torch.from_numpy(base_np).to(dev)
+    frames = torch.empty((BATCH, H, W, 3), dtype=torch.uint8, device=dev)
+    for i in range(BATCH):
+        frames[i] = torch.roll(base[i % uniq], i // uniq, dims=0)
+    masks = torch.empty((BATCH, 1, H, W), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    g = ip.ImgProc(W, H, device=local_rank, n_slots=1, max_batch=BATCH)
+    g.set_pipeline(post_blur_k=5, morph=ip.MORPH_BASELINE, force_unfused=args.unfused)
+    g.set_ranges([DEFAULT_RANGE])
+    g.set_profiling(True)
+    fused = g.is_fused
+
+    def step():
+        return g.process_batch_device(frames.data_ptr(), H * W * 3, W * 3, W, H, BATCH, masks.data_ptr())
+
+    def fence():
+        g.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        kernel_ms.append(g.last_kernel_ms())  # events were recorded on the library's stream; call is already synced
+    g.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+
+    if args.check and rank == 0:
+        from oracle import Oracle
+
+        i = 9
+        f = frames[i].cpu().numpy()
+        morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in ip.MORPH_BASELINE]
+        exp = Oracle(fast=True).chain(f, post_blur_k=5, morph=morph, ranges=[DEFAULT_RANGE], stages=False)
+        assert (masks[i, 0].cpu().numpy() == exp["mask"][0]).all(), "bench mask != oracle"
+        assert [res[i][0][k] for k in ("m00", "m10", "m01")] == [int(v) for v in exp["moments"][0][:3]]
+
+    if rank == 0:
+        total_frames = BATCH * args.steps * world
+        fps = total_frames / dt
+        k_ms = float(np.mean([m for m, _ in kernel_ms]))
+        launches = kernel_ms[-1][1]
+        achieved = BATCH * ALGO_BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "frames/sec at 1920x1200 BGR8, full chain (5x5 Gaussian, HSV inRange, 3x3 erode+dilate, moments)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1920x1200 BGR8, device-resident batch of 256 frames per GPU per step, "
+                                   "post-HSV 5x5 Gaussian + inRange + erode3 + dilate3 + moments, masks written to HBM",
+                       "frames_per_step_per_gpu": BATCH, "width": W, "height": H,
+                       "path": "fused" if fused else f"stage-by-stage ({launches} launches per step)",
+                       "sharding": f"frames x{world} ranks, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "ipf::k_fused_chain" if fused else "all stage kernels of one step",
+                         "kernel_ms_per_launch": k_ms, "algorithmic_bytes_per_launch": BATCH * ALGO_BYTES_PER_FRAME},
+            "achieved_gbps_whole_job": fps * ALGO_BYTES_PER_FRAME / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(base_np, 4 * threads, threads)
+        print(json.dumps(out), flush=True)
+    g.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
