@@ -30,7 +30,8 @@ class Morph(C.Structure):
 
 class Pipeline(C.Structure):
     _fields_ = [("encoding", C.c_int), ("pre_blur_k", C.c_int), ("post_blur_k", C.c_int), ("n_morph", C.c_int),
-                ("morph", Morph * MAX_MORPH), ("keep_stages", C.c_int), ("force_unfused", C.c_int)]
+                ("morph", Morph * MAX_MORPH), ("keep_stages", C.c_int), ("force_unfused", C.c_int),
+                ("second_order", C.c_int)]
 
 
 class Moments(C.Structure):

@@ -159,14 +159,17 @@ void make_bounds(int n, const int32_t (*lo)[3], const int32_t (*hi)[3], ipk::Bou
         }
 }
 
-void finish_moments(const unsigned long long *m, imgproc_moments &o)
+void finish_moments(const unsigned long long *m, imgproc_moments &o, bool second = true)
 {
-    o.m00 = m[0]; o.m10 = m[1]; o.m01 = m[2]; o.m20 = m[3]; o.m11 = m[4]; o.m02 = m[5];
+    o.m00 = m[0]; o.m10 = m[1]; o.m01 = m[2];
+    o.m20 = second ? m[3] : 0; o.m11 = second ? m[4] : 0; o.m02 = second ? m[5] : 0;
     o.found = m[0] != 0;
     o.reserved = 0;
+    o.theta = 0.0;
     if (o.found) {
         o.cx = (double)m[1] / (double)m[0];
         o.cy = (double)m[2] / (double)m[0];
+        if (!second) return;
         long double n = (long double)m[0];
         long double mu20 = (long double)m[3] - (long double)m[1] * (long double)m[1] / n;
         long double mu02 = (long double)m[5] - (long double)m[2] * (long double)m[2] / n;
@@ -474,7 +477,7 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
     const int nr = p.bounds.n;
     HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, c->stream));
-    if (p.fused_ok) {
+    if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask)) {
         HIPCHK(c, ipf::launch_fused(p.fused, s.d_raw, 0, rowb, w, h, 1, s.d_mask, s.d_mom, c->d_tables, c->stream));
     } else {
         rc = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr);
@@ -502,7 +505,7 @@ IMGPROC_API int imgproc_wait(imgproc_ctx *c, int slot, imgproc_result *out)
     s.in_flight = false;
     memset(out, 0, sizeof *out);
     out->n_ranges = c->plan.bounds.n;
-    for (int r = 0; r < out->n_ranges; r++) finish_moments(s.h_mom + 6 * r, out->r[r]);
+    for (int r = 0; r < out->n_ranges; r++) finish_moments(s.h_mom + 6 * r, out->r[r], c->plan.pipe.second_order != 0);
     return IMGPROC_OK;
 }
 
@@ -584,7 +587,7 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
     c->prof_valid = false;
     c->prof_launches = 0;
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_k0, c->stream));
-    if (p.fused_ok) {
+    if (p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
         HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks,
                                     c->d_mom_batch, c->d_tables, c->stream));
         c->prof_launches = 1;
@@ -606,7 +609,7 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
         for (int i = 0; i < n; i++) {
             memset(&out[i], 0, sizeof out[i]);
             out[i].n_ranges = nr;
-            for (int r = 0; r < nr; r++) finish_moments(c->h_mom_batch + ((size_t)i * nr + r) * 6, out[i].r[r]);
+            for (int r = 0; r < nr; r++) finish_moments(c->h_mom_batch + ((size_t)i * nr + r) * 6, out[i].r[r], p.pipe.second_order != 0);
         }
     }
     return IMGPROC_OK;

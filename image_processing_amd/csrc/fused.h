@@ -20,6 +20,10 @@ struct FusedPlan {
 bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const ipk::Taps &pre, const ipk::Taps &post,
                 const ipk::Bounds &bounds, FusedPlan *out);
 
+// launch-time conditions (alignment, width % 4) the fused kernel needs; false -> run stage by stage
+bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
+                      const void *d_masks);
+
 // frames: n frames at d_frames + i*frame_stride; masks (may be null): [n][n_ranges][h][w]; moments added into
 // d_mom[n][n_ranges][6] (caller zeroes)
 hipError_t launch_fused(const FusedPlan &plan, const ipk::u8 *d_frames, size_t frame_stride, size_t row_stride, int w,

@@ -1,17 +1,425 @@
+// Fused chain kernel for gfx950: BGR/RGB -> HSV -> [5x5 Gaussian] -> inRange -> up to two 3x3 rect
+// erode/dilate -> mask bytes + raster moments, one launch for a whole batch of frames.
+//
+// Replaces, for the pipelines plan_fused() accepts, the OpenCV call sequence of
+// objectPolygonPath.cpp:183-188 / pose_estimate.cpp:203-206 (cvtColor, GaussianBlur 5x5, inRange,
+// erode, dilate) and the m00/m10/m01 sums of moments() (objectPolygonPath.cpp:449-450).
+// Arithmetic: SURVEY.md Appendix A, bit-exact with the stage kernels and the oracle.
+//
+// Design (MI355X: HBM-bound u8 work, no MFMA):
+//  * One WAVE owns a strip of 256 columns (4 px per lane = one 12-byte load per lane and row; lanes 0
+//    and 63 are halo) and marches down a segment of rows.  Waves never talk to each other: no
+//    barriers after the table load, no LDS tiles, no vertical halo re-computation inside a segment.
+//  * HSV rows live in a register ring; the vertical 1-4-6-4-1 pass runs on it, the horizontal pass
+//    gets its +-2 px neighbours from the adjacent lanes with DPP wave shifts.
+//  * Pixels are kept as packed 16-bit fields (H|S<<16 per pixel, V pairs), so every Gaussian add /
+//    shift-add processes two values per VALU op; sums stay < 2^16 per field (max 255*256+128).
+//    The single rounding (x+128)>>8 is folded in as +8 in the vertical pass and never materialised:
+//    inRange compares the 8.8 field against (lo<<8, hi<<8|255).
+//  * inRange results are shifted into a per-lane 4-col x 8-row bit tile; 3x3 erode/dilate are a dozen
+//    bit operations on that tile (horizontal neighbours again by DPP), 32 pixels per op.
+//  * Moments are popcounts of the final tile; mask bytes are expanded from the tile rows and stored
+//    as one dword per lane and row (256 B per wave row, coalesced).
 #include "fused.h"
 
 namespace ipf {
 
-bool plan_fused(const imgproc_pipeline &, const ipk::Element *, const ipk::Taps &, const ipk::Taps &,
-                const ipk::Bounds &, FusedPlan *)
+using ipk::u8;
+
+constexpr int STRIP_VALID = 248;  // valid output columns per wave (lanes 1..62)
+constexpr int MAX_NR = 2;
+
+struct Args {
+    const u8 *frames;
+    size_t frame_stride, row_stride;
+    u8 *masks;
+    unsigned long long *mom;
+    const int *tables;
+    int w, h, n;
+    int seg_rows, n_segs, n_strips, total_items;
+    int op0, op1;  // 0 erode3, 1 dilate3, 2 identity (one-row delay only)
+    uint32_t hs_lo[MAX_NR], hs_hi[MAX_NR], v_lo[MAX_NR], v_hi[MAX_NR];
+};
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t from_left(uint32_t v)  // lane l <- lane l-1
 {
-    return false;
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t from_right(uint32_t v)  // lane l <- lane l+1
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int sh)  // ({hi:lo} >> sh) low 32
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+__device__ __forceinline__ uint32_t pk_clamp(uint32_t x, uint32_t lo, uint32_t hi)
+{
+    us2 a = __builtin_bit_cast(us2, x), l = __builtin_bit_cast(us2, lo), h = __builtin_bit_cast(us2, hi);
+    us2 c = __builtin_elementwise_min(__builtin_elementwise_max(a, l), h);
+    return __builtin_bit_cast(uint32_t, c);
+}
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * (n - 1) - p;
+    return p;
 }
 
-hipError_t launch_fused(const FusedPlan &, const ipk::u8 *, size_t, size_t, int, int, int, ipk::u8 *,
-                        unsigned long long *, const int *, hipStream_t)
+// One pixel of cvtColor(BGR2HSV).  Inputs are the channel bytes times 4 (they double as
+// byte offsets into the LDS reciprocal tables); (d*4*sdiv + 2^13) >> 14 == (d*sdiv + 2^11) >> 12.
+template <bool RGB>
+__device__ __forceinline__ void hsv_px(uint32_t c0, uint32_t c1, uint32_t c2, const char *tab, uint32_t &hs,
+                                       uint32_t &v)
 {
-    return hipErrorNotSupported;
+    const int b4 = RGB ? c2 : c0, g4 = c1, r4 = RGB ? c0 : c2;
+    const int v4 = max(max(b4, g4), r4), m4 = min(min(b4, g4), r4), d4 = v4 - m4;
+    const int sdiv = *reinterpret_cast<const int *>(tab + v4);
+    const int hdiv = *reinterpret_cast<const int *>(tab + 1024 + d4);
+    const uint32_t s = (__umul24((uint32_t)d4, (uint32_t)sdiv) + 8192u) >> 14;
+    const int hr = g4 - b4, hg = (b4 - r4) + 2 * d4, hb = (r4 - g4) + 4 * d4;
+    const int hh = (v4 == r4) ? hr : (v4 == g4) ? hg : hb;
+    const int x = __mul24(hh, hdiv) + 8192;
+    const int h = (x >> 14) + ((x >> 31) & 180);
+    hs = (uint32_t)h | (s << 16);
+    v = (uint32_t)v4 >> 2;
+}
+
+struct Row {  // one row of this lane's 4 pixels as packed 16-bit fields
+    uint32_t hs[4];  // px k: H | S<<16
+    uint32_t v[2];   // (V0,V1), (V2,V3)
+};
+
+template <bool RGB>
+__device__ __forceinline__ void hsv_row(const uint32_t (&w)[3], const char *tab, Row &o)
+{
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    uint32_t vv[4];
+    hsv_px<RGB>((w0 & 0xFF) << 2, ((w0 >> 8) & 0xFF) << 2, ((w0 >> 16) & 0xFF) << 2, tab, o.hs[0], vv[0]);
+    hsv_px<RGB>((w0 >> 24) << 2, (w1 & 0xFF) << 2, ((w1 >> 8) & 0xFF) << 2, tab, o.hs[1], vv[1]);
+    hsv_px<RGB>(((w1 >> 16) & 0xFF) << 2, (w1 >> 24) << 2, (w2 & 0xFF) << 2, tab, o.hs[2], vv[2]);
+    hsv_px<RGB>(((w2 >> 8) & 0xFF) << 2, ((w2 >> 16) & 0xFF) << 2, (w2 >> 24) << 2, tab, o.hs[3], vv[3]);
+    o.v[0] = vv[0] | (vv[1] << 16);
+    o.v[1] = vv[2] | (vv[3] << 16);
+}
+
+// vertical 1-4-6-4-1 on packed fields, +8 per field (the folded rounding)
+__device__ __forceinline__ uint32_t vert5(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4)
+{
+    uint32_t t = a0 + a4 + 0x00080008u;
+    t += (a1 + a3) << 2;
+    return __umul24(a2, 6u) + t;  // a2 <= 0x00FF00FF < 2^24
+}
+// horizontal 1-4-6-4-1: a,b = k-2,k+2; c,d = k-1,k+1; e = k
+__device__ __forceinline__ uint32_t horz5(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e)
+{
+    uint32_t t = a + b;
+    t += (c + d + e) << 2;
+    return t + (e << 1);
+}
+
+// 3x3 rect erode/dilate (or identity) on a 4-col x 8-row bit tile; causal in rows (one-row delay).
+// Tile layout: row position p (0 = oldest) at bits 4*(7-p)..+3, column c at bit c of the nibble.
+// `inv` = bits outside the image (neutral for the op).  prev = this stage's previous horizontal result.
+__device__ __forceinline__ uint32_t morph3(uint32_t cur, uint32_t &prev, int kind, uint32_t inv)
+{
+    if (kind == 2) {
+        uint32_t out = alignbit(prev, cur, 4);
+        prev = cur;
+        return out;
+    }
+    const uint32_t km = kind ? 0xFFFFFFFFu : 0u;  // dilate(X) = ~erode(~X)
+    const uint32_t x = (cur ^ km) | inv;
+    const uint32_t xl = from_left(x), xr = from_right(x);
+    const uint32_t l = ((x << 1) & 0xEEEEEEEEu) | ((xl >> 3) & 0x11111111u);
+    const uint32_t r = ((x >> 1) & 0x77777777u) | ((xr << 3) & 0x88888888u);
+    const uint32_t hh = x & l & r;
+    const uint32_t out = hh & alignbit(prev, hh, 4) & alignbit(prev, hh, 8);
+    prev = hh;
+    return out ^ km;
+}
+
+__device__ __forceinline__ uint32_t rows_outside(int y0, int lo, int hi)  // nibble mask of positions with y not in [lo,hi)
+{
+    if (y0 >= lo && y0 + 8 <= hi) return 0u;
+    uint32_t m = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+        if (y0 + p < lo || y0 + p >= hi) m |= 0xFu << (4 * (7 - p));
+    return m;
+}
+
+template <int POST_K, bool RGB, int NR, int PF>
+__global__ __launch_bounds__(256) void k_fused_chain(const Args a)
+{
+    __shared__ int s_tab[512];
+    s_tab[threadIdx.x] = a.tables[threadIdx.x];
+    s_tab[threadIdx.x + 256] = a.tables[threadIdx.x + 256];
+    __syncthreads();
+    const char *tab = reinterpret_cast<const char *>(s_tab);
+
+    const int lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= a.total_items) return;
+    const int strip = item % a.n_strips;
+    const int rest = item / a.n_strips;
+    const int seg = rest % a.n_segs;
+    const int frame = rest / a.n_segs;
+    const int w = a.w, h = a.h;
+    const int ys = seg * a.seg_rows;
+    const int ye = min(ys + a.seg_rows, h);
+    const int x0 = strip * STRIP_VALID - 4 + lane * 4;
+    const int xl = min(max(x0, 0), w - 4);
+    const bool in_image = x0 >= 0 && x0 < w;
+    const bool lane_out = in_image && lane >= 1 && lane <= 62;
+    const bool strip_left = strip == 0;
+    const bool strip_right = strip * STRIP_VALID + 252 >= w;
+    const bool lb = x0 == 0, rb = x0 == w - 4;
+    const uint32_t colinv = in_image ? 0u : 0xFFFFFFFFu;
+
+    const u8 *fbase = a.frames + (size_t)frame * a.frame_stride + (size_t)xl * 3;
+    const size_t rs = a.row_stride;
+
+    constexpr int LEAD = POST_K == 5 ? 2 : 0;  // blur needs rows t-2..t+2
+    const int t0 = ys - 2;                     // first inRange row of the tile stream
+    const int r_first = t0 - LEAD;             // first fed row
+    const int n_batches = (ye - ys + 4 + 7) / 8;
+
+    uint32_t raw[8][3];
+    Row ring[8];
+    auto load_row = [&](int slot, int f) {
+        const int r = reflect101(min(r_first + f, 2 * h + 6), h);
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(fbase + (size_t)r * rs);
+        raw[slot][0] = p[0];
+        raw[slot][1] = p[1];
+        raw[slot][2] = p[2];
+    };
+
+    // fed row f uses raw/ring slot (f + 8 - 2*LEAD) & 7, so that the main step j = f - 2*LEAD uses slot j & 7
+    constexpr int S0 = (8 - 2 * LEAD) & 7;
+#pragma unroll
+    for (int q = 0; q < PF; q++) load_row((S0 + q) & 7, q);
+    if (POST_K == 5) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            load_row((S0 + q + PF) & 7, q + PF);
+            hsv_row<RGB>(raw[(S0 + q) & 7], tab, ring[(S0 + q) & 7]);
+        }
+    }
+
+    uint32_t acc[NR], prev1[NR], prev2[NR];
+    uint32_t m00[NR], m10[NR], m01[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = prev1[r] = prev2[r] = m00[r] = m10[r] = m01[r] = 0;
+
+    const size_t plane = (size_t)w * h;
+    u8 *mbase = a.masks ? a.masks + (size_t)frame * NR * plane + x0 : nullptr;
+
+    for (int b = 0; b < n_batches; b++) {
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+            const int f = 2 * LEAD + b * 8 + rr;  // fed index of this step's newest row
+            load_row((rr + PF) & 7, f + PF);
+            hsv_row<RGB>(raw[rr], tab, ring[rr]);
+            uint32_t o_hs[4], o_v[2];
+            if (POST_K == 5) {
+                uint32_t c_hs[4], c_v[2];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    c_hs[k] = vert5(ring[(rr + 4) & 7].hs[k], ring[(rr + 5) & 7].hs[k], ring[(rr + 6) & 7].hs[k],
+                                    ring[(rr + 7) & 7].hs[k], ring[rr].hs[k]);
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    c_v[k] = vert5(ring[(rr + 4) & 7].v[k], ring[(rr + 5) & 7].v[k], ring[(rr + 6) & 7].v[k],
+                                   ring[(rr + 7) & 7].v[k], ring[rr].v[k]);
+                uint32_t l2 = from_left(c_hs[2]), l3 = from_left(c_hs[3]);
+                uint32_t r0 = from_right(c_hs[0]), r1 = from_right(c_hs[1]);
+                uint32_t vl = from_left(c_v[1]), vr = from_right(c_v[0]);
+                const uint32_t m2 = alignbit(c_v[1], c_v[0], 16);  // (V1,V2)
+                if (strip_left || strip_right) {                   // reflect-101 at the image's left/right edge
+                    const uint32_t sw = alignbit(m2, m2, 16);      // (V2,V1)
+                    if (lb) { l2 = c_hs[2]; l3 = c_hs[1]; vl = sw; }
+                    if (rb) { r0 = c_hs[2]; r1 = c_hs[1]; vr = sw; }
+                }
+                o_hs[0] = horz5(l2, c_hs[2], l3, c_hs[1], c_hs[0]);
+                o_hs[1] = horz5(l3, c_hs[3], c_hs[0], c_hs[2], c_hs[1]);
+                o_hs[2] = horz5(c_hs[0], r0, c_hs[1], c_hs[3], c_hs[2]);
+                o_hs[3] = horz5(c_hs[1], r1, c_hs[2], r0, c_hs[3]);
+                const uint32_t m1 = alignbit(c_v[0], vl, 16);  // (V-1,V0)
+                const uint32_t m3 = alignbit(vr, c_v[1], 16);  // (V3,V4)
+                o_v[0] = horz5(vl, c_v[1], m1, m2, c_v[0]);
+                o_v[1] = horz5(c_v[0], vr, m2, m3, c_v[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) o_hs[k] = ring[rr].hs[k];
+                o_v[0] = ring[rr].v[0];
+                o_v[1] = ring[rr].v[1];
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const uint32_t vlo = a.v_lo[r], vhi = a.v_hi[r];
+                uint32_t t = acc[r];
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const uint32_t vk = (k & 1) ? (o_v[k >> 1] >> 16) : (o_v[k >> 1] & 0xFFFFu);
+                    const bool ok = (pk_clamp(o_hs[k], a.hs_lo[r], a.hs_hi[r]) == o_hs[k]) && vk >= vlo && vk <= vhi;
+                    t = t + t + (ok ? 1u : 0u);
+                }
+                acc[r] = t;
+            }
+        }
+        // ---- one 4x8 tile per range is complete: morphology, store, moments ----
+        const int yt = t0 + b * 8;  // image row of tile position 0 at the inRange stage
+        const uint32_t inv1 = colinv | rows_outside(yt, 0, h);
+        const uint32_t inv2 = colinv | rows_outside(yt - 1, 0, h);
+        const uint32_t keep = lane_out ? ~rows_outside(yt - 2, ys, ye) : 0u;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            uint32_t t = morph3(acc[r], prev1[r], a.op0, inv1);
+            t = morph3(t, prev2[r], a.op1, inv2);
+            const uint32_t fm = t & keep;
+            if (mbase) {
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    const int y = yt - 2 + p;
+                    if (y >= ys && y < ye && lane_out) {
+                        const uint32_t nib = (t >> (4 * (7 - p))) & 15u;
+                        // nibble bit c -> bit 0 of byte c, then v_perm selectors 0x0C (0x00) / 0x0D (0xFF)
+                        const uint32_t sel = (__umul24(nib, 0x00204081u) & 0x01010101u) | 0x0C0C0C0Cu;
+                        const uint32_t bytes = __builtin_amdgcn_perm(0u, 0u, sel);
+                        *reinterpret_cast<uint32_t *>(mbase + (size_t)r * plane + (size_t)y * w) = bytes;
+                    }
+                }
+            }
+            const uint32_t cnt = __popc(fm);
+            const uint32_t csum = __popc(fm & 0xAAAAAAAAu) + 2 * __popc(fm & 0xCCCCCCCCu);
+            const uint32_t q = __popc(fm & 0xF0F0F0F0u) + 2 * __popc(fm & 0xFF00FF00u) + 4 * __popc(fm & 0xFFFF0000u);
+            m00[r] += cnt;
+            m10[r] += (uint32_t)x0 * cnt + csum;
+            m01[r] += (uint32_t)((yt - 2 + 7) * (int)cnt - (int)q);
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        unsigned long long s0 = m00[r], s1 = m10[r], s2 = m01[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_down(s0, off, 64);
+            s1 += __shfl_down(s1, off, 64);
+            s2 += __shfl_down(s2, off, 64);
+        }
+        if (lane == 0) {
+            unsigned long long *o = a.mom + ((size_t)frame * NR + r) * 6;
+            if (s0) {
+                atomicAdd(o + 0, s0);
+                atomicAdd(o + 1, s1);
+                atomicAdd(o + 2, s2);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// planning / launch
+// ---------------------------------------------------------------------------------------------
+bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const ipk::Taps &, const ipk::Taps &,
+                const ipk::Bounds &bounds, FusedPlan *out)
+{
+    if (pipe.encoding != IMGPROC_ENC_BGR8 && pipe.encoding != IMGPROC_ENC_RGB8) return false;
+    if (pipe.pre_blur_k > 1) return false;
+    if (!(pipe.post_blur_k <= 1 || pipe.post_blur_k == 5)) return false;
+    if (pipe.second_order) return false;
+    if (pipe.n_morph > 2 || bounds.n < 1 || bounds.n > MAX_NR) return false;
+    FusedPlan p{};
+    p.bidx = pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0;
+    p.post_k = pipe.post_blur_k == 5 ? 5 : 1;
+    p.n_groups = pipe.n_morph;
+    p.kind[0] = p.kind[1] = 2;
+    for (int i = 0; i < pipe.n_morph; i++) {
+        const ipk::Element &e = elems[i];
+        if (!e.is_rect || e.kw != 3 || e.kh != 3 || e.ax != 1 || e.ay != 1) return false;
+        p.kind[i] = pipe.morph[i].kind == IMGPROC_DILATE ? 1 : 0;
+    }
+    p.bounds = bounds;
+    *out = p;
+    return true;
+}
+
+bool can_launch_fused(const FusedPlan &, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
+                      const void *d_masks)
+{
+    if (w < 4 || (w & 3) || h < 1 || w > 16384 || h > 16384) return false;
+    if (((uintptr_t)d_frames & 3) || (frame_stride & 3) || (row_stride & 3) || ((uintptr_t)d_masks & 3)) return false;
+    return true;
+}
+
+static int g_seg_rows_override = -1;
+
+hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_stride, size_t row_stride, int w,
+                        int h, int n, u8 *d_masks, unsigned long long *d_mom, const int *d_tables,
+                        hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    if (g_seg_rows_override < 0) {
+        const char *e = getenv("IMGPROC_SEG_ROWS");
+        g_seg_rows_override = e ? atoi(e) : 0;
+    }
+    Args a{};
+    a.frames = d_frames;
+    a.frame_stride = frame_stride;
+    a.row_stride = row_stride;
+    a.masks = d_masks;
+    a.mom = d_mom;
+    a.tables = d_tables;
+    a.w = w;
+    a.h = h;
+    a.n = n;
+    int target = g_seg_rows_override > 0 ? g_seg_rows_override : 148;
+    a.n_segs = (h + target - 1) / target;
+    a.seg_rows = (h + a.n_segs - 1) / a.n_segs;
+    if (a.seg_rows > 512) {  // u32 moment partials are sized for <= 512 rows per segment
+        a.seg_rows = 512;
+        a.n_segs = (h + 511) / 512;
+    }
+    a.n_strips = (w + STRIP_VALID - 1) / STRIP_VALID;
+    a.total_items = a.n_strips * a.n_segs * n;
+    a.op0 = plan.kind[0];
+    a.op1 = plan.kind[1];
+    const int nr = plan.bounds.n;
+    const int sh = plan.post_k == 5 ? 8 : 0;  // blurred fields are 8.8
+    for (int r = 0; r < nr; r++) {
+        const auto &B = plan.bounds;
+        bool never = false;
+        for (int c = 0; c < 3; c++) never |= B.lo[r][c] > B.hi[r][c];
+        auto lo16 = [&](int c) { return (uint32_t)B.lo[r][c] << sh; };
+        auto hi16 = [&](int c) { return ((uint32_t)B.hi[r][c] << sh) | (sh ? 0xFFu : 0u); };
+        if (never) {  // an empty channel interval empties the whole mask: make the V test unsatisfiable
+            a.hs_lo[r] = 0;
+            a.hs_hi[r] = 0xFFFFFFFFu;
+            a.v_lo[r] = 0xFFFFu;
+            a.v_hi[r] = 0;
+        } else {
+            a.hs_lo[r] = lo16(0) | (lo16(1) << 16);
+            a.hs_hi[r] = hi16(0) | (hi16(1) << 16);
+            a.v_lo[r] = lo16(2);
+            a.v_hi[r] = hi16(2);
+        }
+    }
+    const dim3 grid((a.total_items + 3) / 4), block(256);
+    const bool rgb = plan.bidx == 2;
+#define LAUNCH(PK, RGBV, NRV) hipLaunchKernelGGL((k_fused_chain<PK, RGBV, NRV, 3>), grid, block, 0, stream, a)
+    if (plan.post_k == 5) {
+        if (nr == 1) { if (rgb) LAUNCH(5, true, 1); else LAUNCH(5, false, 1); }
+        else         { if (rgb) LAUNCH(5, true, 2); else LAUNCH(5, false, 2); }
+    } else {
+        if (nr == 1) { if (rgb) LAUNCH(1, true, 1); else LAUNCH(1, false, 1); }
+        else         { if (rgb) LAUNCH(1, true, 2); else LAUNCH(1, false, 2); }
+    }
+#undef LAUNCH
+    return hipGetLastError();
 }
 
 }  // namespace ipf

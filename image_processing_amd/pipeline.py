@@ -83,7 +83,7 @@ class ImgProc:
 
     # -- configuration -----------------------------------------------------------------------
     def set_pipeline(self, *, encoding=L.ENC_BGR8, pre_blur_k=0, post_blur_k=0, morph=(), keep_stages=False,
-                     force_unfused=False):
+                     force_unfused=False, second_order=False):
         p = L.Pipeline()
         p.encoding, p.pre_blur_k, p.post_blur_k = encoding, pre_blur_k, post_blur_k
         p.n_morph = len(morph)
@@ -98,7 +98,7 @@ class ImgProc:
                 arr = np.ascontiguousarray(m.custom, dtype=np.uint8)
                 self._keep.append(arr)
                 pm.custom = arr.ctypes.data_as(L.u8p)
-        p.keep_stages, p.force_unfused = int(keep_stages), int(force_unfused)
+        p.keep_stages, p.force_unfused, p.second_order = int(keep_stages), int(force_unfused), int(second_order)
         self._chk(self.lib.imgproc_set_pipeline(self._ctx, C.byref(p)), "imgproc_set_pipeline")
         self.encoding = encoding
 

@@ -98,6 +98,7 @@ typedef struct imgproc_pipeline {
     imgproc_morph morph[IMGPROC_MAX_MORPH];
     int keep_stages;   /* keep every stage output on the device for imgproc_fetch_stage */
     int force_unfused; /* run stage-by-stage kernels even when a fused kernel exists (parity tests) */
+    int second_order;  /* also compute m20/m11/m02 and theta; 0: they are reported as 0 */
 } imgproc_pipeline;
 
 /* Raster moments of the final mask (== cv::moments(mask, true)); all sums are exact integers.

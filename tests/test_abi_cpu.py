@@ -42,7 +42,7 @@ def test_struct_layout_matches_header():
     # sizes the C side computes for the same structs (LP64): guards the ctypes mirror
     assert C.sizeof(L.Config) == 20
     assert C.sizeof(L.Morph) == 32
-    assert C.sizeof(L.Pipeline) == 16 + 32 * 32 + 8
+    assert C.sizeof(L.Pipeline) == 16 + 32 * 32 + 16
     assert C.sizeof(L.Moments) == 6 * 8 + 3 * 8 + 8
     assert C.sizeof(L.Result) == 8 + 8 * C.sizeof(L.Moments)
 
