@@ -45,11 +45,11 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t from_left(uint32_t v)  // lane l <- lane l-1
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xF, 0xF, true);  // bound_ctrl: lane 0 reads 0
 }
 __device__ __forceinline__ uint32_t from_right(uint32_t v)  // lane l <- lane l+1
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int sh)  // ({hi:lo} >> sh) low 32
 {
@@ -61,11 +61,34 @@ __device__ __forceinline__ uint32_t pk_clamp(uint32_t x, uint32_t lo, uint32_t h
     us2 c = __builtin_elementwise_min(__builtin_elementwise_max(a, l), h);
     return __builtin_bit_cast(uint32_t, c);
 }
-__device__ __forceinline__ int reflect101(int p, int n)
+// hipcc does not reliably select the 24-bit multiply-adds (it falls back to quarter-rate v_mul_lo_u32 /
+// v_mad_u64_u32), so they are spelled out.
+__device__ __forceinline__ int mad_i24(int a, int b, int c)
 {
-    if (n == 1) return 0;
-    while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * (n - 1) - p;
-    return p;
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// t = 2*t + bit, the bit coming straight from the compare's lane mask (carry-in)
+__device__ __forceinline__ uint32_t shift_in(uint32_t t, unsigned long long m)
+{
+    uint32_t r;
+    asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(t), "s"(m) : "vcc");
+    return r;
+}
+// BORDER_REFLECT_101 for the rows this kernel can ask for (|overshoot| < h for every row a valid output
+// depends on; rows beyond that are prefetch overshoot and only need to stay inside the frame)
+__device__ __forceinline__ int reflect_row(int r, int h)
+{
+    r = abs(r);
+    r = r >= h ? 2 * (h - 1) - r : r;
+    return min(abs(r), h - 1);
 }
 
 // One pixel of cvtColor(BGR2HSV).  Inputs are the channel bytes times 4 (they double as
@@ -76,14 +99,16 @@ __device__ __forceinline__ void hsv_px(uint32_t c0, uint32_t c1, uint32_t c2, co
 {
     const int b4 = RGB ? c2 : c0, g4 = c1, r4 = RGB ? c0 : c2;
     const int v4 = max(max(b4, g4), r4), m4 = min(min(b4, g4), r4), d4 = v4 - m4;
-    const int sdiv = *reinterpret_cast<const int *>(tab + v4);
-    const int hdiv = *reinterpret_cast<const int *>(tab + 1024 + d4);
-    const uint32_t s = (__umul24((uint32_t)d4, (uint32_t)sdiv) + 8192u) >> 14;
-    const int hr = g4 - b4, hg = (b4 - r4) + 2 * d4, hb = (r4 - g4) + 4 * d4;
+    const int sdiv4 = *reinterpret_cast<const int *>(tab + v4);        // 4 * sdiv[v]
+    const int hdiv = *reinterpret_cast<const int *>(tab + 1024 + d4);  // hdiv180[diff]
+    // S << 16 == ((d*sdiv + 2^11) >> 12) << 16 == (4d * 4sdiv + 2^15) & 0xFFFF0000   (4d*4sdiv <= 2^24)
+    const uint32_t s16 = mad_u24((uint32_t)d4, (uint32_t)sdiv4, 32768u) & 0xFFFF0000u;
+    int hr = g4 - b4, hg = (b4 - r4) + 2 * d4, hb = (r4 - g4) + 4 * d4;
+    asm("" : "+v"(hr), "+v"(hg), "+v"(hb));  // keep the three candidates live: selects, not branches
     const int hh = (v4 == r4) ? hr : (v4 == g4) ? hg : hb;
-    const int x = __mul24(hh, hdiv) + 8192;
-    const int h = (x >> 14) + ((x >> 31) & 180);
-    hs = (uint32_t)h | (s << 16);
+    const int x = mad_i24(hh, hdiv, 8192);
+    const int h = mad_i24(x >> 31, -180, x >> 14);  // (x >> 14) + (x < 0 ? 180 : 0)
+    hs = (uint32_t)h | s16;
     v = (uint32_t)v4 >> 2;
 }
 
@@ -110,7 +135,7 @@ __device__ __forceinline__ uint32_t vert5(uint32_t a0, uint32_t a1, uint32_t a2,
 {
     uint32_t t = a0 + a4 + 0x00080008u;
     t += (a1 + a3) << 2;
-    return __umul24(a2, 6u) + t;  // a2 <= 0x00FF00FF < 2^24
+    return mad_u24(a2, 6u, t);  // a2 <= 0x00FF00FF < 2^24
 }
 // horizontal 1-4-6-4-1: a,b = k-2,k+2; c,d = k-1,k+1; e = k
 __device__ __forceinline__ uint32_t horz5(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e)
@@ -155,7 +180,7 @@ template <int POST_K, bool RGB, int NR, int PF>
 __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 {
     __shared__ int s_tab[512];
-    s_tab[threadIdx.x] = a.tables[threadIdx.x];
+    s_tab[threadIdx.x] = a.tables[threadIdx.x] * 4;  // 4*sdiv (see hsv_px)
     s_tab[threadIdx.x + 256] = a.tables[threadIdx.x + 256];
     __syncthreads();
     const char *tab = reinterpret_cast<const char *>(s_tab);
@@ -179,8 +204,10 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const bool lb = x0 == 0, rb = x0 == w - 4;
     const uint32_t colinv = in_image ? 0u : 0xFFFFFFFFu;
 
-    const u8 *fbase = a.frames + (size_t)frame * a.frame_stride + (size_t)xl * 3;
-    const size_t rs = a.row_stride;
+    // uniform (SGPR) frame pointer + 32-bit per-lane byte offset: loads use the saddr form
+    const u8 *fptr = a.frames + (size_t)frame * a.frame_stride;
+    const uint32_t lane_off = (uint32_t)xl * 3u;
+    const uint32_t rs = (uint32_t)a.row_stride;  // byte offsets inside one frame fit 32 bits (checked at launch)
 
     constexpr int LEAD = POST_K == 5 ? 2 : 0;  // blur needs rows t-2..t+2
     const int t0 = ys - 2;                     // first inRange row of the tile stream
@@ -190,8 +217,9 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     uint32_t raw[8][3];
     Row ring[8];
     auto load_row = [&](int slot, int f) {
-        const int r = reflect101(min(r_first + f, 2 * h + 6), h);
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(fbase + (size_t)r * rs);
+        const int r = reflect_row(r_first + f, h);
+        const uint32_t off = (uint32_t)r * rs + lane_off;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(fptr + off);
         raw[slot][0] = p[0];
         raw[slot][1] = p[1];
         raw[slot][2] = p[2];
@@ -215,7 +243,8 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     for (int r = 0; r < NR; r++) acc[r] = prev1[r] = prev2[r] = m00[r] = m10[r] = m01[r] = 0;
 
     const size_t plane = (size_t)w * h;
-    u8 *mbase = a.masks ? a.masks + (size_t)frame * NR * plane + x0 : nullptr;
+    u8 *mptr = a.masks ? a.masks + (size_t)frame * NR * plane : nullptr;  // uniform
+    const uint32_t mask_off = (uint32_t)max(x0, 0);
 
     for (int b = 0; b < n_batches; b++) {
 #pragma unroll
@@ -264,8 +293,10 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 #pragma unroll
                 for (int k = 3; k >= 0; k--) {
                     const uint32_t vk = (k & 1) ? (o_v[k >> 1] >> 16) : (o_v[k >> 1] & 0xFFFFu);
-                    const bool ok = (pk_clamp(o_hs[k], a.hs_lo[r], a.hs_hi[r]) == o_hs[k]) && vk >= vlo && vk <= vhi;
-                    t = t + t + (ok ? 1u : 0u);
+                    // three compares write lane masks; the AND is scalar work
+                    const unsigned long long ok = __builtin_amdgcn_ballot_w64(pk_clamp(o_hs[k], a.hs_lo[r], a.hs_hi[r]) == o_hs[k]) &
+                                                  __builtin_amdgcn_ballot_w64(vk >= vlo) & __builtin_amdgcn_ballot_w64(vk <= vhi);
+                    t = shift_in(t, ok);
                 }
                 acc[r] = t;
             }
@@ -280,16 +311,25 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
             uint32_t t = morph3(acc[r], prev1[r], a.op0, inv1);
             t = morph3(t, prev2[r], a.op1, inv2);
             const uint32_t fm = t & keep;
-            if (mbase) {
+            if (mptr) {
+                // nibble bit c -> selector byte c in {0,1} -> byte 0x00 / 0xFF of the constant 0x0000FF00
+                auto expand = [](uint32_t tile, int p) {
+                    const uint32_t nib = (tile >> (4 * (7 - p))) & 15u;
+                    return __builtin_amdgcn_perm(0u, 0x0000FF00u, __umul24(nib, 0x00204081u) & 0x01010101u);
+                };
+                u8 *rowp = mptr + (size_t)r * plane + (size_t)(yt - 2) * w;  // uniform
+                if (yt - 2 >= ys && yt - 2 + 8 <= ye) {  // whole tile inside the segment (the common case)
+                    if (lane_out) {
 #pragma unroll
-                for (int p = 0; p < 8; p++) {
-                    const int y = yt - 2 + p;
-                    if (y >= ys && y < ye && lane_out) {
-                        const uint32_t nib = (t >> (4 * (7 - p))) & 15u;
-                        // nibble bit c -> bit 0 of byte c, then v_perm selectors 0x0C (0x00) / 0x0D (0xFF)
-                        const uint32_t sel = (__umul24(nib, 0x00204081u) & 0x01010101u) | 0x0C0C0C0Cu;
-                        const uint32_t bytes = __builtin_amdgcn_perm(0u, 0u, sel);
-                        *reinterpret_cast<uint32_t *>(mbase + (size_t)r * plane + (size_t)y * w) = bytes;
+                        for (int p = 0; p < 8; p++)
+                            *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = expand(t, p);
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 8; p++) {
+                        const int y = yt - 2 + p;
+                        if (y >= ys && y < ye && lane_out)
+                            *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = expand(t, p);
                     }
                 }
             }
@@ -297,8 +337,8 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
             const uint32_t csum = __popc(fm & 0xAAAAAAAAu) + 2 * __popc(fm & 0xCCCCCCCCu);
             const uint32_t q = __popc(fm & 0xF0F0F0F0u) + 2 * __popc(fm & 0xFF00FF00u) + 4 * __popc(fm & 0xFFFF0000u);
             m00[r] += cnt;
-            m10[r] += (uint32_t)x0 * cnt + csum;
-            m01[r] += (uint32_t)((yt - 2 + 7) * (int)cnt - (int)q);
+            m10[r] = mad_u24((uint32_t)x0, cnt, m10[r]) + csum;   // x0 < 2^24 wherever cnt != 0
+            m01[r] = mad_u24((uint32_t)(yt + 5), cnt, m01[r]) - q;  // sum of rows = (yt-2+7)*cnt - q; yt+5 > 0 wherever cnt != 0
         }
     }
 
@@ -352,6 +392,7 @@ bool can_launch_fused(const FusedPlan &, const void *d_frames, size_t frame_stri
                       const void *d_masks)
 {
     if (w < 4 || (w & 3) || h < 1 || w > 16384 || h > 16384) return false;
+    if ((unsigned long long)row_stride * (unsigned long long)h >= (1ull << 32)) return false;  // 32-bit in-frame offsets
     if (((uintptr_t)d_frames & 3) || (frame_stride & 3) || (row_stride & 3) || ((uintptr_t)d_masks & 3)) return false;
     return true;
 }
