@@ -96,8 +96,12 @@ def main() -> None:
     g.set_profiling(True)
     fused = g.is_fused
 
+    from image_processing_amd import _lib as L
+
+    raw = (L.Result * BATCH)()  # the C ABI fills this host array with the per-frame moments / centroids
+
     def step():
-        return g.process_batch_device(frames.data_ptr(), H * W * 3, W * 3, W, H, BATCH, masks.data_ptr())
+        return g.process_batch_device(frames.data_ptr(), H * W * 3, W * 3, W, H, BATCH, masks.data_ptr(), raw=raw)
 
     def fence():
         g.synchronize()
@@ -130,7 +134,7 @@ def main() -> None:
         morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in ip.MORPH_BASELINE]
         exp = Oracle(fast=True).chain(f, post_blur_k=5, morph=morph, ranges=[DEFAULT_RANGE], stages=False)
         assert (masks[i, 0].cpu().numpy() == exp["mask"][0]).all(), "bench mask != oracle"
-        assert [res[i][0][k] for k in ("m00", "m10", "m01")] == [int(v) for v in exp["moments"][0][:3]]
+        assert [getattr(res[i].r[0], k) for k in ("m00", "m10", "m01")] == [int(v) for v in exp["moments"][0][:3]]
 
     if rank == 0:
         total_frames = BATCH * args.steps * world

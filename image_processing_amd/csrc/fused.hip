@@ -51,6 +51,19 @@ __device__ __forceinline__ uint32_t from_right(uint32_t v)  // lane l <- lane l+
 {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xF, 0xF, true);
 }
+// x[lane-1] + y and x[lane+1] + y in one instruction (lane 0 / lane 63 read 0)
+__device__ __forceinline__ uint32_t add_from_left(uint32_t x, uint32_t y)
+{
+    uint32_t r;
+    asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_from_right(uint32_t x, uint32_t y)
+{
+    uint32_t r;
+    asm("v_add_u32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int sh)  // ({hi:lo} >> sh) low 32
 {
     return __builtin_amdgcn_alignbit(hi, lo, sh);
@@ -73,6 +86,18 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int max3u(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int min3u(int a, int b, int c)
+{
+    int r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 // t = 2*t + bit, the bit coming straight from the compare's lane mask (carry-in)
@@ -98,7 +123,7 @@ __device__ __forceinline__ void hsv_px(uint32_t c0, uint32_t c1, uint32_t c2, co
                                        uint32_t &v)
 {
     const int b4 = RGB ? c2 : c0, g4 = c1, r4 = RGB ? c0 : c2;
-    const int v4 = max(max(b4, g4), r4), m4 = min(min(b4, g4), r4), d4 = v4 - m4;
+    const int v4 = max3u(b4, g4, r4), m4 = min3u(b4, g4, r4), d4 = v4 - m4;
     const int sdiv4 = *reinterpret_cast<const int *>(tab + v4);        // 4 * sdiv[v]
     const int hdiv = *reinterpret_cast<const int *>(tab + 1024 + d4);  // hdiv180[diff]
     // S << 16 == ((d*sdiv + 2^11) >> 12) << 16 == (4d * 4sdiv + 2^15) & 0xFFFF0000   (4d*4sdiv <= 2^24)
@@ -109,7 +134,7 @@ __device__ __forceinline__ void hsv_px(uint32_t c0, uint32_t c1, uint32_t c2, co
     const int x = mad_i24(hh, hdiv, 8192);
     const int h = mad_i24(x >> 31, -180, x >> 14);  // (x >> 14) + (x < 0 ? 180 : 0)
     hs = (uint32_t)h | s16;
-    v = (uint32_t)v4 >> 2;
+    v = (uint32_t)v4;  // still times 4; hsv_row unscales a packed pair with one shift
 }
 
 struct Row {  // one row of this lane's 4 pixels as packed 16-bit fields
@@ -126,8 +151,8 @@ __device__ __forceinline__ void hsv_row(const uint32_t (&w)[3], const char *tab,
     hsv_px<RGB>((w0 >> 24) << 2, (w1 & 0xFF) << 2, ((w1 >> 8) & 0xFF) << 2, tab, o.hs[1], vv[1]);
     hsv_px<RGB>(((w1 >> 16) & 0xFF) << 2, (w1 >> 24) << 2, (w2 & 0xFF) << 2, tab, o.hs[2], vv[2]);
     hsv_px<RGB>(((w2 >> 8) & 0xFF) << 2, ((w2 >> 16) & 0xFF) << 2, (w2 >> 24) << 2, tab, o.hs[3], vv[3]);
-    o.v[0] = vv[0] | (vv[1] << 16);
-    o.v[1] = vv[2] | (vv[3] << 16);
+    o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;  // 4*V0 is a multiple of 4: no bits cross the field boundary
+    o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
 }
 
 // vertical 1-4-6-4-1 on packed fields, +8 per field (the folded rounding)
@@ -143,6 +168,12 @@ __device__ __forceinline__ uint32_t horz5(uint32_t a, uint32_t b, uint32_t c, ui
     uint32_t t = a + b;
     t += (c + d + e) << 2;
     return t + (e << 1);
+}
+
+// same with the outer pair already summed
+__device__ __forceinline__ uint32_t horz5s(uint32_t ab, uint32_t c, uint32_t d, uint32_t e)
+{
+    return ab + ((c + d + e) << 2) + (e << 1);
 }
 
 // 3x3 rect erode/dilate (or identity) on a 4-col x 8-row bit tile; causal in rows (one-row delay).
@@ -179,9 +210,12 @@ __device__ __forceinline__ uint32_t rows_outside(int y0, int lo, int hi)  // nib
 template <int POST_K, bool RGB, int NR, int PF>
 __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 {
-    __shared__ int s_tab[512];
+    __shared__ int s_tab[512 + 16];
     s_tab[threadIdx.x] = a.tables[threadIdx.x] * 4;  // 4*sdiv (see hsv_px)
     s_tab[threadIdx.x + 256] = a.tables[threadIdx.x + 256];
+    if (threadIdx.x < 16)  // nibble -> four mask bytes (bit c -> byte c = 0x00 / 0xFF)
+        s_tab[512 + threadIdx.x] = (int)(((threadIdx.x & 1) ? 0xFFu : 0u) | ((threadIdx.x & 2) ? 0xFF00u : 0u) |
+                                         ((threadIdx.x & 4) ? 0xFF0000u : 0u) | ((threadIdx.x & 8) ? 0xFF000000u : 0u));
     __syncthreads();
     const char *tab = reinterpret_cast<const char *>(s_tab);
 
@@ -201,7 +235,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const bool lane_out = in_image && lane >= 1 && lane <= 62;
     const bool strip_left = strip == 0;
     const bool strip_right = strip * STRIP_VALID + 252 >= w;
-    const bool lb = x0 == 0, rb = x0 == w - 4;
+    const bool lb_halo = x0 == -4, rb_halo = x0 == w;  // halo lanes just outside the left / right image border
     const uint32_t colinv = in_image ? 0u : 0xFFFFFFFFu;
 
     // uniform (SGPR) frame pointer + 32-bit per-lane byte offset: loads use the saddr form
@@ -263,23 +297,30 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
                 for (int k = 0; k < 2; k++)
                     c_v[k] = vert5(ring[(rr + 4) & 7].v[k], ring[(rr + 5) & 7].v[k], ring[(rr + 6) & 7].v[k],
                                    ring[(rr + 7) & 7].v[k], ring[rr].v[k]);
-                uint32_t l2 = from_left(c_hs[2]), l3 = from_left(c_hs[3]);
-                uint32_t r0 = from_right(c_hs[0]), r1 = from_right(c_hs[1]);
-                uint32_t vl = from_left(c_v[1]), vr = from_right(c_v[0]);
-                const uint32_t m2 = alignbit(c_v[1], c_v[0], 16);  // (V1,V2)
-                if (strip_left || strip_right) {                   // reflect-101 at the image's left/right edge
-                    const uint32_t sw = alignbit(m2, m2, 16);      // (V2,V1)
-                    if (lb) { l2 = c_hs[2]; l3 = c_hs[1]; vl = sw; }
-                    if (rb) { r0 = c_hs[2]; r1 = c_hs[1]; vr = sw; }
+                if (strip_left || strip_right) {
+                    // BORDER_REFLECT_101 at the image's left/right edge: give the halo lane next to the border
+                    // lane the mirrored columns, so the DPP fetches below read col -1 = col 1, col -2 = col 2
+                    // (and col w = col w-2, col w+1 = col w-3).  Those halo lanes never produce output.
+                    const uint32_t m2b = alignbit(c_v[1], c_v[0], 16);  // (V1,V2)
+                    const uint32_t sw = alignbit(m2b, m2b, 16);         // (V2,V1)
+                    const uint32_t a2 = from_right(c_hs[2]), a1 = from_right(c_hs[1]), asw = from_right(sw);
+                    const uint32_t b2 = from_left(c_hs[2]), b1 = from_left(c_hs[1]), bsw = from_left(sw);
+                    if (lb_halo) { c_hs[2] = a2; c_hs[3] = a1; c_v[1] = asw; }
+                    if (rb_halo) { c_hs[0] = b2; c_hs[1] = b1; c_v[0] = bsw; }
                 }
-                o_hs[0] = horz5(l2, c_hs[2], l3, c_hs[1], c_hs[0]);
-                o_hs[1] = horz5(l3, c_hs[3], c_hs[0], c_hs[2], c_hs[1]);
-                o_hs[2] = horz5(c_hs[0], r0, c_hs[1], c_hs[3], c_hs[2]);
-                o_hs[3] = horz5(c_hs[1], r1, c_hs[2], r0, c_hs[3]);
+                const uint32_t l3 = from_left(c_hs[3]), r0 = from_right(c_hs[0]);
+                const uint32_t vl = from_left(c_v[1]), vr = from_right(c_v[0]);
+                const uint32_t m2 = alignbit(c_v[1], c_v[0], 16);  // (V1,V2)
+                // the k-2 / k+2 terms that cross lanes are single-use: written as plain adds so the DPP fetch
+                // folds into the add (v_add_u32_dpp)
+                o_hs[0] = horz5s(add_from_left(c_hs[2], c_hs[2]), l3, c_hs[1], c_hs[0]);
+                o_hs[1] = horz5s(l3 + c_hs[3], c_hs[0], c_hs[2], c_hs[1]);
+                o_hs[2] = horz5s(c_hs[0] + r0, c_hs[1], c_hs[3], c_hs[2]);
+                o_hs[3] = horz5s(add_from_right(c_hs[1], c_hs[1]), c_hs[2], r0, c_hs[3]);
                 const uint32_t m1 = alignbit(c_v[0], vl, 16);  // (V-1,V0)
                 const uint32_t m3 = alignbit(vr, c_v[1], 16);  // (V3,V4)
-                o_v[0] = horz5(vl, c_v[1], m1, m2, c_v[0]);
-                o_v[1] = horz5(c_v[0], vr, m2, m3, c_v[1]);
+                o_v[0] = horz5s(vl + c_v[1], m1, m2, c_v[0]);
+                o_v[1] = horz5s(c_v[0] + vr, m2, m3, c_v[1]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) o_hs[k] = ring[rr].hs[k];
@@ -312,10 +353,11 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
             t = morph3(t, prev2[r], a.op1, inv2);
             const uint32_t fm = t & keep;
             if (mptr) {
-                // nibble bit c -> selector byte c in {0,1} -> byte 0x00 / 0xFF of the constant 0x0000FF00
-                auto expand = [](uint32_t tile, int p) {
-                    const uint32_t nib = (tile >> (4 * (7 - p))) & 15u;
-                    return __builtin_amdgcn_perm(0u, 0x0000FF00u, __umul24(nib, 0x00204081u) & 0x01010101u);
+                // tile row p -> nibble*4 -> LDS lookup of the four mask bytes (two VALU ops + one ds_read per row)
+                auto expand = [&](uint32_t tile, int p) {
+                    const int sh = 4 * (7 - p) - 2;
+                    const uint32_t idx = (sh >= 0 ? (tile >> sh) : (tile << 2)) & 0x3Cu;
+                    return *reinterpret_cast<const uint32_t *>(tab + 2048 + idx);
                 };
                 u8 *rowp = mptr + (size_t)r * plane + (size_t)(yt - 2) * w;  // uniform
                 if (yt - 2 >= ys && yt - 2 + 8 <= ye) {  // whole tile inside the segment (the common case)
@@ -418,7 +460,7 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     a.w = w;
     a.h = h;
     a.n = n;
-    int target = g_seg_rows_override > 0 ? g_seg_rows_override : 148;
+    int target = g_seg_rows_override > 0 ? g_seg_rows_override : 200;
     a.n_segs = (h + target - 1) / target;
     a.seg_rows = (h + a.n_segs - 1) / a.n_segs;
     if (a.seg_rows > 512) {  // u32 moment partials are sized for <= 512 rows per segment

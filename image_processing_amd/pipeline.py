@@ -151,12 +151,13 @@ class ImgProc:
         return [[_moments_to_dict(res[i].r[j]) for j in range(res[i].n_ranges)] for i in range(n)]
 
     def process_batch_device(self, d_frames: int, frame_stride: int, row_stride: int, w: int, h: int, n: int,
-                             d_masks: int | None = None, want_results: bool = True):
-        res = (L.Result * n)() if want_results else None
+                             d_masks: int | None = None, want_results: bool = True, raw=None):
+        """raw: a preallocated (L.Result * n)() array to fill and return as is (no per-frame Python objects)."""
+        res = raw if raw is not None else ((L.Result * n)() if want_results else None)
         self._chk(self.lib.imgproc_process_batch_device(self._ctx, d_frames, frame_stride, row_stride, w, h, n,
                                                         d_masks, res), "imgproc_process_batch_device")
-        if res is None:
-            return None
+        if res is None or raw is not None:
+            return res
         return [[_moments_to_dict(res[i].r[j]) for j in range(res[i].n_ranges)] for i in range(n)]
 
     # -- device memory -------------------------------------------------------------------------
