@@ -126,6 +126,14 @@ def main() -> None:
         dt = float(t.item())
         dist.barrier()
 
+    # host-side gather of the last step's per-frame moments, ordered by global frame id (rank-major blocks).
+    # Outside the timed region: the data path itself has no inter-rank step.
+    from image_processing_amd.shard import centroids, gather_by_frame
+
+    local = np.array([[res[i].r[0].m00, res[i].r[0].m10, res[i].r[0].m01] for i in range(BATCH)], np.int64)
+    gathered = gather_by_frame(local, BATCH * world, rank, world, dist)
+    n_found = int((centroids(gathered)[:, 0] >= 0).sum()) if rank == 0 else 0
+
     if args.check and rank == 0:
         from oracle import Oracle
 
@@ -151,7 +159,8 @@ def main() -> None:
                                    "post-HSV 5x5 Gaussian + inRange + erode3 + dilate3 + moments, masks written to HBM",
                        "frames_per_step_per_gpu": BATCH, "width": W, "height": H,
                        "path": "fused" if fused else f"stage-by-stage ({launches} launches per step)",
-                       "sharding": f"frames x{world} ranks, no collective"},
+                       "sharding": f"frames x{world} ranks, no collective; {BATCH * world} centroids gathered on rank 0 "
+                                   f"after the timed region ({n_found} with an object)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "ipf::k_fused_chain" if fused else "all stage kernels of one step",

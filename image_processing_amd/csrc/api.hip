@@ -477,8 +477,13 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
     const int nr = p.bounds.n;
     HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, c->stream));
-    if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask)) {
-        HIPCHK(c, ipf::launch_fused(p.fused, s.d_raw, 0, rowb, w, h, 1, s.d_mask, s.d_mom, c->d_tables, c->stream));
+    if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, (size_t)w * 3, w, h, s.d_mask)) {
+        const u8 *src = s.d_raw;
+        if (p.fused.bayer) {  // Bayer front-end: demosaic to BGR (stage kernel), then the fused chain
+            HIPCHK(c, ipk::launch_demosaic_rggb(s.d_raw, rowb, s.d_bgr, (size_t)w * 3, w, h, c->stream));
+            src = s.d_bgr;
+        }
+        HIPCHK(c, ipf::launch_fused(p.fused, src, 0, (size_t)w * 3, w, h, 1, s.d_mask, s.d_mom, c->d_tables, c->stream));
     } else {
         rc = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr);
         if (rc) return rc;
@@ -587,10 +592,19 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
     c->prof_valid = false;
     c->prof_launches = 0;
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_k0, c->stream));
-    if (p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
+    if (p.fused_ok && !p.fused.bayer && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
         HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks,
                                     c->d_mom_batch, c->d_tables, c->stream));
         c->prof_launches = 1;
+    } else if (p.fused_ok && p.fused.bayer && ipf::can_launch_fused(p.fused, s.d_bgr, 0, (size_t)w * 3, w, h, d_masks)) {
+        for (int i = 0; i < n; i++) {  // demosaic + fused chain per frame (two launches per frame)
+            HIPCHK(c, ipk::launch_demosaic_rggb((const u8 *)d_frames + (size_t)i * frame_stride, row_stride, s.d_bgr,
+                                                (size_t)w * 3, w, h, c->stream));
+            u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : nullptr;
+            HIPCHK(c, ipf::launch_fused(p.fused, s.d_bgr, 0, (size_t)w * 3, w, h, 1, mout, c->d_mom_batch + (size_t)i * nr * 6,
+                                        c->d_tables, c->stream));
+            c->prof_launches += 2;
+        }
     } else {
         for (int i = 0; i < n; i++) {
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;

@@ -9,6 +9,7 @@ namespace ipf {
 struct FusedPlan {
     int variant;      // kernel specialisation chosen by plan_fused
     int bidx;         // 0 BGR input, 2 RGB input
+    int bayer;        // input is BayerRG8: the caller demosaics to BGR first (k_demosaic_rggb), then this kernel runs
     int post_k;       // post-HSV blur ksize (1 = none)
     int n_groups;     // merged morphology groups
     int kind[8];      // per group: 0 erode, 1 dilate

@@ -410,13 +410,13 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const ipk::Taps &, const ipk::Taps &,
                 const ipk::Bounds &bounds, FusedPlan *out)
 {
-    if (pipe.encoding != IMGPROC_ENC_BGR8 && pipe.encoding != IMGPROC_ENC_RGB8) return false;
     if (pipe.pre_blur_k > 1) return false;
     if (!(pipe.post_blur_k <= 1 || pipe.post_blur_k == 5)) return false;
     if (pipe.second_order) return false;
     if (pipe.n_morph > 2 || bounds.n < 1 || bounds.n > MAX_NR) return false;
     FusedPlan p{};
     p.bidx = pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0;
+    p.bayer = pipe.encoding == IMGPROC_ENC_BAYER_RGGB8;
     p.post_k = pipe.post_blur_k == 5 ? 5 : 1;
     p.n_groups = pipe.n_morph;
     p.kind[0] = p.kind[1] = 2;

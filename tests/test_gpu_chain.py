@@ -124,6 +124,33 @@ def test_bayer_chain(gpu, oracle):
     check_moments(res[0], exp["moments"][0])
 
 
+@pytest.mark.parametrize("hw", [(100, 256), (480, 640)])
+def test_bayer_chain_fused_backend(gpu, oracle, hw):
+    """BayerRG8 input with a fusable tail: demosaic kernel + fused chain (BASELINE config 3's operators)."""
+    h, w = hw
+    raws = np.stack([synth_bayer_rggb(w, h, i) for i in range(3)])
+    gpu.set_pipeline(encoding=L.ENC_BAYER_RGGB8, post_blur_k=5, morph=ip.MORPH_BASELINE)
+    gpu.set_ranges([DEFAULT_RANGE])
+    assert gpu.is_fused
+    exps = [oracle.chain(r, encoding=2, post_blur_k=5, morph=morph_tuples(ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE],
+                         stages=False) for r in raws]
+    res = gpu.process(raws[0])
+    assert (gpu.fetch_stage(0, L.STAGE_MASK) == exps[0]["mask"][0]).all()
+    check_moments(res[0], exps[0]["moments"][0])
+    d_in = gpu.dev_alloc(raws.nbytes)
+    d_out = gpu.dev_alloc(3 * w * h)
+    try:
+        gpu.dev_upload(d_in, raws)
+        res = gpu.process_batch_device(d_in, w * h, w, w, h, 3, d_out)
+        masks = gpu.dev_download(d_out, (3, 1, h, w))
+        for i in range(3):
+            assert (masks[i, 0] == exps[i]["mask"][0]).all()
+            check_moments(res[i][0], exps[i]["moments"][0])
+    finally:
+        gpu.dev_free(d_in)
+        gpu.dev_free(d_out)
+
+
 def test_stress_pipeline_small(gpu, oracle):
     """BASELINE config 5's operators (15x15 Gaussian, 9x9 ellipse, 8 ranges) at a size the oracle finishes fast."""
     bands = [(20 * i, 20 * i + 19) for i in range(8)]
