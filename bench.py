@@ -74,6 +74,8 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("BENCH_ALL_RANKS_ON_GPU0") == "1":  # rehearsal of the N>1 path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

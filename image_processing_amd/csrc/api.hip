@@ -27,6 +27,10 @@ struct Slot {
     u8 *d_thresh = nullptr, *d_mask = nullptr, *d_m0 = nullptr, *d_m1 = nullptr, *d_masked = nullptr;
     unsigned long long *d_mom = nullptr, *h_mom = nullptr;
     hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    hipStream_t stream = nullptr;          // every slot runs its frame on its own stream: slot k+1's upload overlaps slot k's kernels
+    hipGraphExec_t graph_exec = nullptr;   // captured {H2D, memset, chain kernels, D2H of moments} for (w, h, plan epoch)
+    int graph_w = 0, graph_h = 0;
+    unsigned graph_epoch = 0;
     int w = 0, h = 0;
     bool in_flight = false, has_frame = false;
     const u8 *blur_ptr = nullptr, *hsv_ptr = nullptr, *bgr_ptr = nullptr;  // where each kept stage lives
@@ -58,6 +62,8 @@ struct imgproc_ctx {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     bool prof_valid = false;
     int prof_launches = 0;
+    unsigned plan_epoch = 1;  // bumped by set_pipeline / set_ranges: invalidates the slots' captured graphs
+    int graph_mode = 0;  // IMGPROC_GRAPH: 0 direct launches (default, measured faster), 1 replay a captured hipGraph per frame, 2 graph only for the stage-by-stage chain
     char err[512] = {0};
 };
 
@@ -191,6 +197,8 @@ void free_slot(Slot &s)
     if (s.d_mom) (void)hipFree(s.d_mom);
     if (s.ev_up) (void)hipEventDestroy(s.ev_up);
     if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    if (s.graph_exec) (void)hipGraphExecDestroy(s.graph_exec);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
     s = Slot();
 }
 
@@ -212,17 +220,17 @@ int alloc_slot(imgproc_ctx *c, Slot &s)
     HIPCHK(c, hipMalloc((void **)&s.d_mom, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES));
     HIPCHK(c, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     return 0;
 }
 
 // Stage-by-stage chain for one frame whose raw bytes are at d_frame (device).  Final masks land in
 // d_masks_out (n_ranges planes of w*h, tight), moments are ADDED into d_mom (caller zeroes).
 int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, int w, int h, u8 *d_masks_out,
-                unsigned long long *d_mom, int *launches)
+                unsigned long long *d_mom, int *launches, hipStream_t st)
 {
     const Plan &p = c->plan;
     const size_t t3 = (size_t)w * 3, px = (size_t)w * h;
-    hipStream_t st = c->stream;
     const u8 *cur = d_frame;
     size_t cur_stride = row_stride;
     int bidx = p.pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0;
@@ -334,6 +342,7 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
     if (!c) return IMGPROC_ENOMEM;
     c->cfg = *cfg;
     if (c->cfg.max_batch < 1) c->cfg.max_batch = 1;
+    if (const char *e = getenv("IMGPROC_GRAPH")) c->graph_mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
     auto build = [&]() -> int {
         HIPCHK(c, hipSetDevice(c->cfg.device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -384,7 +393,10 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    for (auto &s : c->slots) free_slot(s);
+    for (auto &s : c->slots) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        free_slot(s);
+    }
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_s0) (void)hipFree(c->d_s0);
     if (c->d_s1) (void)hipFree(c->d_s1);
@@ -434,6 +446,7 @@ IMGPROC_API int imgproc_set_pipeline(imgproc_ctx *c, const imgproc_pipeline *pp)
         np.pipe.morph[i].custom = np.custom[i].empty() ? nullptr : np.custom[i].data();
     }
     c->plan = std::move(np);
+    c->plan_epoch++;
     for (int i = 0; i < c->plan.pipe.n_morph; i++)
         c->plan.pipe.morph[i].custom = c->plan.custom[i].empty() ? nullptr : c->plan.custom[i].data();
     replan_fused(c);
@@ -445,6 +458,7 @@ IMGPROC_API int imgproc_set_ranges(imgproc_ctx *c, int n, const int32_t (*lo)[3]
     if (!c || !lo || !hi) return IMGPROC_EINVAL;
     if (n < 1 || n > IMGPROC_MAX_RANGES) return fail(c, IMGPROC_EINVAL, "n ranges %d (1..%d)", n, IMGPROC_MAX_RANGES);
     make_bounds(n, lo, hi, c->plan.bounds);
+    c->plan_epoch++;
     replan_fused(c);
     return IMGPROC_OK;
 }
@@ -472,26 +486,60 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
         memcpy(s.h_in, data, rowb * h);
     else
         for (int y = 0; y < h; y++) memcpy(s.h_in + (size_t)y * rowb, data + (size_t)y * stride, rowb);
-    HIPCHK(c, hipMemcpyAsync(s.d_raw, s.h_in, rowb * h, hipMemcpyHostToDevice, c->copy_stream));
-    HIPCHK(c, hipEventRecord(s.ev_up, c->copy_stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
-    const int nr = p.bounds.n;
-    HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, c->stream));
-    if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, (size_t)w * 3, w, h, s.d_mask)) {
-        const u8 *src = s.d_raw;
-        if (p.fused.bayer) {  // Bayer front-end: demosaic to BGR (stage kernel), then the fused chain
-            HIPCHK(c, ipk::launch_demosaic_rggb(s.d_raw, rowb, s.d_bgr, (size_t)w * 3, w, h, c->stream));
-            src = s.d_bgr;
+    // The per-frame work {H2D, memset, chain kernels, D2H of the moments} has fixed pointers and sizes for a given
+    // (slot, w, h, plan): it is captured once into a hipGraph and replayed with one hipGraphLaunch per frame.
+    auto enqueue = [&](hipStream_t st) -> int {
+        HIPCHK(c, hipMemcpyAsync(s.d_raw, s.h_in, rowb * h, hipMemcpyHostToDevice, st));
+        const int nr = p.bounds.n;
+        HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, st));
+        if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, (size_t)w * 3, w, h, s.d_mask)) {
+            const u8 *src = s.d_raw;
+            if (p.fused.bayer) {  // Bayer front-end: demosaic to BGR (stage kernel), then the fused chain
+                HIPCHK(c, ipk::launch_demosaic_rggb(s.d_raw, rowb, s.d_bgr, (size_t)w * 3, w, h, st));
+                src = s.d_bgr;
+            }
+            HIPCHK(c, ipf::launch_fused(p.fused, src, 0, (size_t)w * 3, w, h, 1, s.d_mask, s.d_mom, c->d_tables, st));
+        } else {
+            int rc2 = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr, st);
+            if (rc2) return rc2;
+            if (p.pipe.keep_stages)
+                HIPCHK(c, ipk::launch_mask_and(s.bgr_ptr, s.bgr_stride, s.d_mask, (size_t)w, s.d_masked, (size_t)w * 3, w, h, st));
         }
-        HIPCHK(c, ipf::launch_fused(p.fused, src, 0, (size_t)w * 3, w, h, 1, s.d_mask, s.d_mom, c->d_tables, c->stream));
+        HIPCHK(c, hipMemcpyAsync(s.h_mom, s.d_mom, sizeof(unsigned long long) * 6 * nr, hipMemcpyDeviceToHost, st));
+        return 0;
+    };
+    // Measured on MI355X (scripts/stream_bench.py, 1920x1200, 3 slots): replaying the captured graph is SLOWER than
+    // direct launches both for the fused chain (3.8 k vs 4.3 k frames/s) and for polygon_path's 23-launch chain (2.2 k vs
+    // 3.1 k frames/s), so direct launches are the default and the graph path stays selectable.
+    const bool fused_now = p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, (size_t)w * 3, w, h, s.d_mask);
+    if (c->graph_mode == 1 || (c->graph_mode == 2 && !fused_now)) {
+        if (!s.graph_exec || s.graph_w != w || s.graph_h != h || s.graph_epoch != c->plan_epoch) {
+            if (s.graph_exec) {
+                (void)hipGraphExecDestroy(s.graph_exec);
+                s.graph_exec = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue(s.stream);
+            hipError_t e_end = hipStreamEndCapture(s.stream, &g);
+            if (rc) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            HIPCHK(c, e_end);
+            hipError_t e_inst = hipGraphInstantiate(&s.graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            HIPCHK(c, e_inst);
+            s.graph_w = w;
+            s.graph_h = h;
+            s.graph_epoch = c->plan_epoch;
+        }
+        HIPCHK(c, hipGraphLaunch(s.graph_exec, s.stream));
     } else {
-        rc = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr);
+        rc = enqueue(s.stream);
         if (rc) return rc;
-        if (p.pipe.keep_stages)
-            HIPCHK(c, ipk::launch_mask_and(s.bgr_ptr, s.bgr_stride, s.d_mask, (size_t)w, s.d_masked, (size_t)w * 3, w, h, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(s.h_mom, s.d_mom, sizeof(unsigned long long) * 6 * nr, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(s.ev_done, c->stream));
+    HIPCHK(c, hipEventRecord(s.ev_done, s.stream));
     s.w = w;
     s.h = h;
     s.in_flight = true;
@@ -609,7 +657,7 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
         for (int i = 0; i < n; i++) {
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;
             rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)i * frame_stride, row_stride, w, h, mout,
-                             c->d_mom_batch + (size_t)i * nr * 6, &c->prof_launches);
+                             c->d_mom_batch + (size_t)i * nr * 6, &c->prof_launches, c->stream);
             if (rc) return rc;
         }
     }
@@ -861,5 +909,6 @@ IMGPROC_API int imgproc_synchronize(imgproc_ctx *c)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &s : c->slots) HIPCHK(c, hipStreamSynchronize(s.stream));
     return IMGPROC_OK;
 }

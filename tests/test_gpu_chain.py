@@ -233,3 +233,39 @@ def test_full_size_properties(gpu, oracle):
     finally:
         gpu.dev_free(d_in)
         gpu.dev_free(d_out)
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_streaming_graph_replay_and_invalidation(oracle, graph, monkeypatch):
+    """submit/wait with direct launches and with a replayed per-slot hipGraph (IMGPROC_GRAPH=1); new ranges or a new
+    frame size must re-capture."""
+    monkeypatch.setenv("IMGPROC_GRAPH", graph)
+    morph = morph_tuples(ip.MORPH_BASELINE)
+    with ip.ImgProc(640, 480, n_slots=3) as g:
+        g.set_pipeline(post_blur_k=5, morph=ip.MORPH_BASELINE)
+        g.set_ranges([DEFAULT_RANGE])
+        rng2 = ((0, 0, 0), (60, 256, 256))
+        plan = [(640, 480, DEFAULT_RANGE)] * 4 + [(640, 480, rng2)] * 3 + [(320, 200, rng2)] * 3 + [(640, 480, DEFAULT_RANGE)] * 2
+        pending = []
+        for i, (w, h, rng) in enumerate(plan):
+            slot = i % 3
+            if len(pending) == 3:
+                s0, f0, r0 = pending.pop(0)
+                res = g.wait(s0)
+                exp = oracle.chain(f0, post_blur_k=5, morph=morph, ranges=[r0], stages=False)
+                check_moments(res[0], exp["moments"][0])
+                assert (g.fetch_stage(s0, L.STAGE_MASK) == exp["mask"][0]).all()
+            if i and plan[i][2] != plan[i - 1][2]:
+                for s0, f0, r0 in pending:  # ranges are context state: drain before changing them
+                    res = g.wait(s0)
+                    exp = oracle.chain(f0, post_blur_k=5, morph=morph, ranges=[r0], stages=False)
+                    check_moments(res[0], exp["moments"][0])
+                pending = []
+                g.set_ranges([rng])
+            f = synth_frame(w, h, 100 + i)
+            g.submit(slot, f)
+            pending.append((slot, f, rng))
+        for s0, f0, r0 in pending:
+            res = g.wait(s0)
+            exp = oracle.chain(f0, post_blur_k=5, morph=morph, ranges=[r0], stages=False)
+            check_moments(res[0], exp["moments"][0])
