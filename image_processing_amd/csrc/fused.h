@@ -9,6 +9,7 @@ namespace ipf {
 struct FusedPlan {
     int variant;      // kernel specialisation chosen by plan_fused
     int bidx;         // 0 BGR input, 2 RGB input
+    int second_order; // also accumulate m20/m11/m02
     int bayer;        // input is BayerRG8: the caller demosaics to BGR first (k_demosaic_rggb), then this kernel runs
     int post_k;       // post-HSV blur ksize (1 = none)
     int n_groups;     // merged morphology groups

@@ -207,7 +207,7 @@ __device__ __forceinline__ uint32_t rows_outside(int y0, int lo, int hi)  // nib
     return m;
 }
 
-template <int POST_K, bool RGB, int NR, int PF>
+template <int POST_K, bool RGB, int NR, int PF, bool M2>
 __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 {
     __shared__ int s_tab[512 + 16];
@@ -273,8 +273,9 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 
     uint32_t acc[NR], prev1[NR], prev2[NR];
     uint32_t m00[NR], m10[NR], m01[NR];
+    unsigned long long m20[NR], m11[NR], m02[NR];  // second-order sums (only with M2)
 #pragma unroll
-    for (int r = 0; r < NR; r++) acc[r] = prev1[r] = prev2[r] = m00[r] = m10[r] = m01[r] = 0;
+    for (int r = 0; r < NR; r++) acc[r] = prev1[r] = prev2[r] = m00[r] = m10[r] = m01[r] = 0, m20[r] = m11[r] = m02[r] = 0;
 
     const size_t plane = (size_t)w * h;
     u8 *mptr = a.masks ? a.masks + (size_t)frame * NR * plane : nullptr;  // uniform
@@ -381,6 +382,21 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
             m00[r] += cnt;
             m10[r] = mad_u24((uint32_t)x0, cnt, m10[r]) + csum;   // x0 < 2^24 wherever cnt != 0
             m01[r] = mad_u24((uint32_t)(yt + 5), cnt, m01[r]) - q;  // sum of rows = (yt-2+7)*cnt - q; yt+5 > 0 wherever cnt != 0
+            if (M2 && __builtin_amdgcn_ballot_w64(fm != 0)) {
+                // x = x0 + c (c = bit & 3), y = Y7 - u (u = bit >> 2): all second-order sums from popcounts of the tile
+                const uint32_t CA = 0xAAAAAAAAu, CB = 0xCCCCCCCCu, U0 = 0xF0F0F0F0u, U1 = 0xFF00FF00u, U2 = 0xFFFF0000u;
+                const uint32_t c2 = __popc(fm & CA) + 4 * __popc(fm & CB) + 4 * __popc(fm & CA & CB);              // sum c^2
+                const uint32_t u2 = __popc(fm & U0) + 4 * __popc(fm & U1) + 16 * __popc(fm & U2) +
+                                    4 * __popc(fm & U0 & U1) + 8 * __popc(fm & U0 & U2) + 16 * __popc(fm & U1 & U2);  // sum u^2
+                const uint32_t cu = __popc(fm & CA & U0) + 2 * __popc(fm & CA & U1) + 4 * __popc(fm & CA & U2) +
+                                    2 * __popc(fm & CB & U0) + 4 * __popc(fm & CB & U1) + 8 * __popc(fm & CB & U2);   // sum c*u
+                const unsigned long long X = (unsigned long long)(uint32_t)max(x0, 0), Y7 = (unsigned long long)(uint32_t)max(yt + 5, 0);
+                const unsigned long long sy = Y7 * cnt - q;      // sum y
+                const unsigned long long scy = Y7 * csum - cu;   // sum c*y
+                m20[r] += X * X * cnt + 2 * X * csum + c2;
+                m11[r] += X * sy + scy;
+                m02[r] += Y7 * Y7 * cnt + u2 - 2 * Y7 * q;
+            }
         }
     }
 
@@ -401,6 +417,21 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
                 atomicAdd(o + 2, s2);
             }
         }
+        if (M2) {
+            unsigned long long t0 = m20[r], t1 = m11[r], t2 = m02[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                t0 += __shfl_down(t0, off, 64);
+                t1 += __shfl_down(t1, off, 64);
+                t2 += __shfl_down(t2, off, 64);
+            }
+            if (lane == 0 && s0) {
+                unsigned long long *o = a.mom + ((size_t)frame * NR + r) * 6;
+                atomicAdd(o + 3, t0);
+                atomicAdd(o + 4, t1);
+                atomicAdd(o + 5, t2);
+            }
+        }
     }
 }
 
@@ -412,11 +443,11 @@ bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const i
 {
     if (pipe.pre_blur_k > 1) return false;
     if (!(pipe.post_blur_k <= 1 || pipe.post_blur_k == 5)) return false;
-    if (pipe.second_order) return false;
     if (pipe.n_morph > 2 || bounds.n < 1 || bounds.n > MAX_NR) return false;
     FusedPlan p{};
     p.bidx = pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0;
     p.bayer = pipe.encoding == IMGPROC_ENC_BAYER_RGGB8;
+    p.second_order = pipe.second_order != 0;
     p.post_k = pipe.post_blur_k == 5 ? 5 : 1;
     p.n_groups = pipe.n_morph;
     p.kind[0] = p.kind[1] = 2;
@@ -493,7 +524,12 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     }
     const dim3 grid((a.total_items + 3) / 4), block(256);
     const bool rgb = plan.bidx == 2;
-#define LAUNCH(PK, RGBV, NRV) hipLaunchKernelGGL((k_fused_chain<PK, RGBV, NRV, 3>), grid, block, 0, stream, a)
+#define LAUNCH3(PK, RGBV, NRV, M2V) hipLaunchKernelGGL((k_fused_chain<PK, RGBV, NRV, 3, M2V>), grid, block, 0, stream, a)
+#define LAUNCH(PK, RGBV, NRV)                          \
+    do {                                               \
+        if (plan.second_order) LAUNCH3(PK, RGBV, NRV, true); \
+        else LAUNCH3(PK, RGBV, NRV, false);            \
+    } while (0)
     if (plan.post_k == 5) {
         if (nr == 1) { if (rgb) LAUNCH(5, true, 1); else LAUNCH(5, false, 1); }
         else         { if (rgb) LAUNCH(5, true, 2); else LAUNCH(5, false, 2); }
@@ -501,6 +537,7 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
         if (nr == 1) { if (rgb) LAUNCH(1, true, 1); else LAUNCH(1, false, 1); }
         else         { if (rgb) LAUNCH(1, true, 2); else LAUNCH(1, false, 2); }
     }
+#undef LAUNCH3
 #undef LAUNCH
     return hipGetLastError();
 }

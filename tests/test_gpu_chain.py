@@ -269,3 +269,25 @@ def test_streaming_graph_replay_and_invalidation(oracle, graph, monkeypatch):
             res = g.wait(s0)
             exp = oracle.chain(f0, post_blur_k=5, morph=morph, ranges=[r0], stages=False)
             check_moments(res[0], exp["moments"][0])
+
+
+@pytest.mark.parametrize("name", ["baseline", "pose_estimate", "c1"])
+@pytest.mark.parametrize("hw", [(64, 96), (123, 516), (480, 640), (1200, 1920)])
+def test_fused_second_order_moments(gpu, oracle, name, hw):
+    """m20/m11/m02 from the same fused launch, exact integers; theta from the central moments."""
+    if hw == (1200, 1920) and name != "baseline":
+        pytest.skip("full size once")
+    p = PRESETS[name]
+    f = synth_frame(hw[1], hw[0], 21)
+    ranges = [DEFAULT_RANGE, ((0, 0, 0), (90, 256, 256))]
+    gpu.set_pipeline(second_order=True, **p)
+    gpu.set_ranges(ranges)
+    assert gpu.is_fused
+    res = gpu.process(f)
+    exp = oracle.chain(f, post_blur_k=p["post_blur_k"], morph=morph_tuples(p["morph"]), ranges=ranges, stages=False)
+    for r in range(2):
+        check_moments(res[r], exp["moments"][r], second=True)
+        m = [float(v) for v in exp["moments"][r]]
+        if m[0]:
+            mu20, mu02, mu11 = m[3] - m[1] * m[1] / m[0], m[5] - m[2] * m[2] / m[0], m[4] - m[1] * m[2] / m[0]
+            assert abs(res[r]["theta"] - 0.5 * np.arctan2(2 * mu11, mu20 - mu02)) < 1e-9
