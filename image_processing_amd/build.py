@@ -28,7 +28,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_node_sim(force)
     return LIB
+
+
+NODE_SIM = os.path.join(LIBDIR, "node_sim")
+HOST = os.path.join(HERE, "host")
+
+
+def build_node_sim(force: bool = False) -> str:
+    """The ROS-free node simulator (host/node_sim.cpp): plain g++ against the C ABI, no HIP headers needed."""
+    srcs = [os.path.join(HOST, "node_sim.cpp"), os.path.join(HOST, "node_shim.hpp"), LIB]
+    if force or not os.path.exists(NODE_SIM) or any(os.path.getmtime(f) > os.path.getmtime(NODE_SIM) for f in srcs):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-o", NODE_SIM, srcs[0], "-L", LIBDIR,
+                               "-limgproc_hip", "-Wl,-rpath,$ORIGIN"])
+    return NODE_SIM
 
 
 if __name__ == "__main__":
