@@ -14,6 +14,7 @@
 #include "../../include/imgproc.h"
 #include "fused.h"
 #include "kernels.h"
+#include "morphbits.h"
 
 #define IMGPROC_API extern "C" __attribute__((visibility("default")))
 
@@ -45,6 +46,8 @@ struct Plan {
     ipk::Bounds bounds{};
     ipf::FusedPlan fused{};
     bool fused_ok = false;
+    ipm::Plan bm;        // the morph list on bit planes (morphbits.hip)
+    bool bm_ok = false;
 };
 
 }  // namespace
@@ -53,6 +56,7 @@ struct imgproc_ctx {
     imgproc_config cfg{};
     hipStream_t stream = nullptr, copy_stream = nullptr;
     int *d_tables = nullptr;
+    ipm::Group *d_groups = nullptr;  // device copy of plan.bm.groups (32 entries)
     std::vector<Slot> slots;
     Plan plan;
     unsigned long long *d_mom_batch = nullptr, *h_mom_batch = nullptr;
@@ -264,20 +268,26 @@ int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, i
     const int nr = p.bounds.n;
     HIPCHK(c, ipk::launch_in_range(blur, t3, s.d_thresh, (size_t)w, px, w, h, p.bounds, st));
     nl++;
-    for (int r = 0; r < nr; r++) {
-        const u8 *m = s.d_thresh + (size_t)r * px;
-        u8 *final_dst = d_masks_out + (size_t)r * px;
-        for (int i = 0; i < p.pipe.n_morph; i++) {
-            u8 *dst = (i == p.pipe.n_morph - 1) ? final_dst : ((m == s.d_m0) ? s.d_m1 : s.d_m0);
-            HIPCHK(c, ipk::launch_morph(m, (size_t)w, dst, (size_t)w, w, h, p.pipe.morph[i].kind, p.elems[i], st));
-            nl++;
-            m = dst;
-        }
-        if (p.pipe.n_morph == 0) {
-            HIPCHK(c, hipMemcpyAsync(final_dst, m, px, hipMemcpyDeviceToDevice, st));
-        }
-        HIPCHK(c, ipk::launch_moments(final_dst, (size_t)w, w, h, d_mom + 6 * (size_t)r, st));
+    if (p.bm_ok && !p.pipe.force_unfused) {
+        // whole morph list + moments + final masks for all ranges in one launch on bit planes
+        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, d_masks_out, d_mom, w, h, nr, p.pipe.second_order, st));
         nl++;
+    } else {
+        for (int r = 0; r < nr; r++) {
+            const u8 *m = s.d_thresh + (size_t)r * px;
+            u8 *final_dst = d_masks_out + (size_t)r * px;
+            for (int i = 0; i < p.pipe.n_morph; i++) {
+                u8 *dst = (i == p.pipe.n_morph - 1) ? final_dst : ((m == s.d_m0) ? s.d_m1 : s.d_m0);
+                HIPCHK(c, ipk::launch_morph(m, (size_t)w, dst, (size_t)w, w, h, p.pipe.morph[i].kind, p.elems[i], st));
+                nl++;
+                m = dst;
+            }
+            if (p.pipe.n_morph == 0) {
+                HIPCHK(c, hipMemcpyAsync(final_dst, m, px, hipMemcpyDeviceToDevice, st));
+            }
+            HIPCHK(c, ipk::launch_moments(final_dst, (size_t)w, w, h, d_mom + 6 * (size_t)r, st));
+            nl++;
+        }
     }
     if (launches) *launches += nl;
     return 0;
@@ -358,6 +368,7 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
         }
         HIPCHK(c, hipMalloc((void **)&c->d_tables, sizeof tab));
         HIPCHK(c, hipMemcpy(c->d_tables, tab, sizeof tab, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void **)&c->d_groups, sizeof(ipm::Group) * 32));
         const size_t px = (size_t)c->cfg.max_width * c->cfg.max_height;
         HIPCHK(c, hipMalloc((void **)&c->d_s0, px * 3));
         HIPCHK(c, hipMalloc((void **)&c->d_s1, px * 3));
@@ -398,6 +409,7 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
         free_slot(s);
     }
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_groups) (void)hipFree(c->d_groups);
     if (c->d_s0) (void)hipFree(c->d_s0);
     if (c->d_s1) (void)hipFree(c->d_s1);
     if (c->d_s_mom) (void)hipFree(c->d_s_mom);
@@ -450,6 +462,12 @@ IMGPROC_API int imgproc_set_pipeline(imgproc_ctx *c, const imgproc_pipeline *pp)
     for (int i = 0; i < c->plan.pipe.n_morph; i++)
         c->plan.pipe.morph[i].custom = c->plan.custom[i].empty() ? nullptr : c->plan.custom[i].data();
     replan_fused(c);
+    c->plan.bm_ok = c->plan.pipe.n_morph > 0 && ipm::plan_bitmorph(c->plan.pipe, c->plan.elems, &c->plan.bm);
+    if (c->plan.bm_ok) {
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        HIPCHK(c, imgproc_synchronize(c) == IMGPROC_OK ? hipSuccess : hipErrorUnknown);  // nothing in flight may still read the old list
+        HIPCHK(c, hipMemcpy(c->d_groups, c->plan.bm.groups.data(), sizeof(ipm::Group) * c->plan.bm.groups.size(), hipMemcpyHostToDevice));
+    }
     return IMGPROC_OK;
 }
 
