@@ -83,6 +83,7 @@ _SIGS = {
     "imgproc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "imgproc_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "imgproc_pipeline_is_fused": (C.c_int, [C.c_void_p]),
+    "imgproc_pipeline_plan": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "imgproc_synchronize": (C.c_int, [C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

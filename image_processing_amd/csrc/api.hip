@@ -48,6 +48,8 @@ struct Plan {
     bool fused_ok = false;
     ipm::Plan bm;        // the morph list on bit planes (morphbits.hip)
     bool bm_ok = false;
+    ipf::FusedPlan front{};  // [blur3] HSV [blur5] inRange in one kernel, bytes out; bm finishes (two launches per batch)
+    bool front_ok = false;
 };
 
 }  // namespace
@@ -60,6 +62,8 @@ struct imgproc_ctx {
     std::vector<Slot> slots;
     Plan plan;
     unsigned long long *d_mom_batch = nullptr, *h_mom_batch = nullptr;
+    u8 *d_thresh_batch = nullptr;  // inRange planes of a device batch for the front + bit-plane path (grown on demand)
+    size_t thresh_batch_bytes = 0;
     u8 *d_s0 = nullptr, *d_s1 = nullptr;  // scratch for single-stage calls (max frame, 3 ch)
     unsigned long long *d_s_mom = nullptr;
     bool profiling = false;
@@ -410,6 +414,7 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     }
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_groups) (void)hipFree(c->d_groups);
+    if (c->d_thresh_batch) (void)hipFree(c->d_thresh_batch);
     if (c->d_s0) (void)hipFree(c->d_s0);
     if (c->d_s1) (void)hipFree(c->d_s1);
     if (c->d_s_mom) (void)hipFree(c->d_s_mom);
@@ -430,6 +435,7 @@ static void replan_fused(imgproc_ctx *c)
     Plan &p = c->plan;
     p.fused_ok = !p.pipe.force_unfused && !p.pipe.keep_stages &&
                  ipf::plan_fused(p.pipe, p.elems, p.pre, p.post, p.bounds, &p.fused);
+    p.front_ok = !p.fused_ok && !p.pipe.force_unfused && !p.pipe.keep_stages && ipf::plan_front(p.pipe, p.bounds, &p.front);
 }
 
 IMGPROC_API int imgproc_set_pipeline(imgproc_ctx *c, const imgproc_pipeline *pp)
@@ -483,6 +489,21 @@ IMGPROC_API int imgproc_set_ranges(imgproc_ctx *c, int n, const int32_t (*lo)[3]
 
 IMGPROC_API int imgproc_pipeline_is_fused(const imgproc_ctx *c) { return c && c->plan.fused_ok ? 1 : 0; }
 
+IMGPROC_API int imgproc_pipeline_plan(const imgproc_ctx *c, char *buf, size_t len)
+{
+    if (!c || !buf || !len) return IMGPROC_EINVAL;
+    const Plan &p = c->plan;
+    if (p.fused_ok)
+        snprintf(buf, len, "%sfused chain kernel", p.fused.bayer ? "demosaic + " : "");
+    else if (p.front_ok && p.bm_ok)
+        snprintf(buf, len, "%sfront kernel + bit-plane morphology (%d groups)", p.front.bayer ? "demosaic + " : "", (int)p.bm.groups.size());
+    else if (p.bm_ok)
+        snprintf(buf, len, "stage kernels + bit-plane morphology (%d groups)", (int)p.bm.groups.size());
+    else
+        snprintf(buf, len, "stage kernels");
+    return IMGPROC_OK;
+}
+
 // ================================================================================================
 // streaming path
 // ================================================================================================
@@ -517,6 +538,15 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
                 src = s.d_bgr;
             }
             HIPCHK(c, ipf::launch_fused(p.fused, src, 0, (size_t)w * 3, w, h, 1, s.d_mask, s.d_mom, c->d_tables, st));
+        } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, s.d_raw, 0, (size_t)w * 3, w, h, s.d_thresh)) {
+            // front kernel ([blur3] HSV [blur5] inRange -> bytes) + bit-plane back end (morph list, moments, mask)
+            const u8 *src = s.d_raw;
+            if (p.front.bayer) {
+                HIPCHK(c, ipk::launch_demosaic_rggb(s.d_raw, rowb, s.d_bgr, (size_t)w * 3, w, h, st));
+                src = s.d_bgr;
+            }
+            HIPCHK(c, ipf::launch_fused(p.front, src, 0, (size_t)w * 3, w, h, 1, s.d_thresh, nullptr, c->d_tables, st));
+            HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, s.d_mask, s.d_mom, w, h, nr, p.pipe.second_order, st));
         } else {
             int rc2 = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr, st);
             if (rc2) return rc2;
@@ -662,6 +692,33 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
         HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks,
                                     c->d_mom_batch, c->d_tables, c->stream));
         c->prof_launches = 1;
+    } else if (p.front_ok && p.bm_ok &&
+               ipf::can_launch_fused(p.front, p.front.bayer ? (const void *)s.d_bgr : d_frames, p.front.bayer ? 0 : frame_stride,
+                                     p.front.bayer ? (size_t)w * 3 : row_stride, w, h, d_masks)) {
+        const size_t need = (size_t)n * nr * px;
+        if (need > c->thresh_batch_bytes) {  // grown on demand, kept for the life of the context
+            if (c->d_thresh_batch) HIPCHK(c, hipFree(c->d_thresh_batch));
+            c->d_thresh_batch = nullptr;
+            c->thresh_batch_bytes = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_thresh_batch, need));
+            c->thresh_batch_bytes = need;
+        }
+        if (p.front.bayer) {
+            for (int i = 0; i < n; i++) {
+                HIPCHK(c, ipk::launch_demosaic_rggb((const u8 *)d_frames + (size_t)i * frame_stride, row_stride, s.d_bgr,
+                                                    (size_t)w * 3, w, h, c->stream));
+                HIPCHK(c, ipf::launch_fused(p.front, s.d_bgr, 0, (size_t)w * 3, w, h, 1, c->d_thresh_batch + (size_t)i * nr * px,
+                                            nullptr, c->d_tables, c->stream));
+                c->prof_launches += 2;
+            }
+        } else {
+            HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, c->d_thresh_batch,
+                                        nullptr, c->d_tables, c->stream));
+            c->prof_launches += 1;
+        }
+        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, c->d_thresh_batch, (u8 *)d_masks, c->d_mom_batch, w, h, n * nr,
+                                       p.pipe.second_order, c->stream));
+        c->prof_launches += 1;
     } else if (p.fused_ok && p.fused.bayer && ipf::can_launch_fused(p.fused, s.d_bgr, 0, (size_t)w * 3, w, h, d_masks)) {
         for (int i = 0; i < n; i++) {  // demosaic + fused chain per frame (two launches per frame)
             HIPCHK(c, ipk::launch_demosaic_rggb((const u8 *)d_frames + (size_t)i * frame_stride, row_stride, s.d_bgr,

@@ -11,7 +11,9 @@ struct FusedPlan {
     int bidx;         // 0 BGR input, 2 RGB input
     int second_order; // also accumulate m20/m11/m02
     int bayer;        // input is BayerRG8: the caller demosaics to BGR first (k_demosaic_rggb), then this kernel runs
+    int pre_k;        // pre-HSV blur ksize on the raw channels (1 = none, 3)
     int post_k;       // post-HSV blur ksize (1 = none)
+    int mode;         // 0: whole chain in the kernel; 1: front end only (inRange bytes out; morphbits.hip finishes)
     int n_groups;     // merged morphology groups
     int kind[8];      // per group: 0 erode, 1 dilate
     int lo_x[8], hi_x[8], lo_y[8], hi_y[8];  // per group: window offset range [lo, hi] (rect, merged)
@@ -21,6 +23,9 @@ struct FusedPlan {
 // true when the pipeline can run fused; fills *out
 bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const ipk::Taps &pre, const ipk::Taps &post,
                 const ipk::Bounds &bounds, FusedPlan *out);
+
+// front end for pipelines whose morphology list does not fit the fused kernel: [blur3] HSV [blur5] inRange -> bytes
+bool plan_front(const imgproc_pipeline &pipe, const ipk::Bounds &bounds, FusedPlan *out);
 
 // launch-time conditions (alignment, width % 4) the fused kernel needs; false -> run stage by stage
 bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,

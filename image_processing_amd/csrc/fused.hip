@@ -155,6 +155,62 @@ __device__ __forceinline__ void hsv_row(const uint32_t (&w)[3], const char *tab,
     o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
 }
 
+struct RowBGR {  // one raw row of this lane's 4 pixels as packed 16-bit fields (channel order as in memory)
+    uint32_t c01[4];  // px k: c0 | c1<<16
+    uint32_t c2[2];   // (c2 of px0, px1), (px2, px3)
+};
+
+__device__ __forceinline__ void unpack_row(const uint32_t (&w)[3], RowBGR &o)
+{
+    // v_perm_b32 byte selectors: 0-3 = bytes of the second operand, 4-7 = bytes of the first, 0x0C = 0x00
+    o.c01[0] = __builtin_amdgcn_perm(w[0], w[0], 0x0C010C00u);
+    o.c01[1] = __builtin_amdgcn_perm(w[1], w[0], 0x0C040C03u);
+    o.c01[2] = __builtin_amdgcn_perm(w[1], w[1], 0x0C030C02u);
+    o.c01[3] = __builtin_amdgcn_perm(w[2], w[2], 0x0C020C01u);
+    o.c2[0] = __builtin_amdgcn_perm(w[1], w[0], 0x0C050C02u);
+    o.c2[1] = __builtin_amdgcn_perm(w[2], w[2], 0x0C030C00u);
+}
+
+// GaussianBlur 3x3 (objectPolygonPath.cpp:182) on the raw channels, then HSV.  Fields hold 16*value + 8 after the two
+// 1-2-1 passes (the +8 is the folded rounding: +2 per field in the vertical pass times the horizontal weight 4), so the
+// channel value times 4 that hsv_px wants is (field >> 2) & 0x3FC.
+template <bool RGB>
+__device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &r1, const RowBGR &r2, bool border_strip,
+                                                bool lb_halo, bool rb_halo, const char *tab, Row &o)
+{
+    uint32_t v[4], u[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = r0.c01[k] + r2.c01[k] + 0x00020002u + (r1.c01[k] << 1);
+#pragma unroll
+    for (int k = 0; k < 2; k++) u[k] = r0.c2[k] + r2.c2[k] + 0x00020002u + (r1.c2[k] << 1);
+    if (border_strip) {  // BORDER_REFLECT_101 left/right: col -1 = col 1, col w = col w-2 (see the post-blur patch)
+        const uint32_t a1 = from_right(v[1]), au = from_right(u[0]);  // lane+1's px1 / (R0,R1)
+        const uint32_t b2 = from_left(v[2]), bu = from_left(u[1]);    // lane-1's px2 / (R2,R3)
+        if (lb_halo) { v[3] = a1; u[1] = au; }
+        if (rb_halo) { v[0] = b2; u[0] = bu; }
+    }
+    uint32_t h01[4], h2[2];
+    h01[0] = add_from_left(v[3], v[1]) + (v[0] << 1);
+    h01[1] = v[0] + v[2] + (v[1] << 1);
+    h01[2] = v[1] + v[3] + (v[2] << 1);
+    h01[3] = add_from_right(v[0], v[2]) + (v[3] << 1);
+    const uint32_t ul = from_left(u[1]), ur = from_right(u[0]);
+    const uint32_t m1 = alignbit(u[0], ul, 16);    // (c2[-1], c2[0])
+    const uint32_t m2 = alignbit(u[1], u[0], 16);  // (c2[1], c2[2])
+    const uint32_t m3 = alignbit(ur, u[1], 16);    // (c2[3], c2[4])
+    h2[0] = m1 + m2 + (u[0] << 1);
+    h2[1] = m2 + m3 + (u[1] << 1);
+    uint32_t vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t f2 = h2[k >> 1];
+        const uint32_t c2 = (k & 1) ? ((f2 >> 18) & 0x3FCu) : ((f2 >> 2) & 0x3FCu);
+        hsv_px<RGB>((h01[k] >> 2) & 0x3FCu, (h01[k] >> 18) & 0x3FCu, c2, tab, o.hs[k], vv[k]);
+    }
+    o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;
+    o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
+}
+
 // vertical 1-4-6-4-1 on packed fields, +8 per field (the folded rounding)
 __device__ __forceinline__ uint32_t vert5(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4)
 {
@@ -207,7 +263,9 @@ __device__ __forceinline__ uint32_t rows_outside(int y0, int lo, int hi)  // nib
     return m;
 }
 
-template <int POST_K, bool RGB, int NR, int PF, bool M2>
+// MODE 0: whole chain (up to two 3x3 ops, moments, final mask).  MODE 1: front end only: the inRange output is
+// written as 0/255 bytes to a.masks (the bit-plane back end, morphbits.hip, runs the morph list and the moments).
+template <int PRE_K, int POST_K, bool RGB, int NR, int PF, bool M2, int MODE>
 __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 {
     __shared__ int s_tab[512 + 16];
@@ -243,13 +301,27 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const uint32_t lane_off = (uint32_t)xl * 3u;
     const uint32_t rs = (uint32_t)a.row_stride;  // byte offsets inside one frame fit 32 bits (checked at launch)
 
-    constexpr int LEAD = POST_K == 5 ? 2 : 0;  // blur needs rows t-2..t+2
-    const int t0 = ys - 2;                     // first inRange row of the tile stream
+    constexpr int LEAD = (POST_K == 5 ? 2 : 0) + (PRE_K == 3 ? 1 : 0);  // rows of look-ahead the blurs need
+    constexpr int MH = MODE == 0 ? 2 : 0;      // row delay of the two morphology stages
+    const int t0 = ys - MH;                    // first inRange row of the tile stream
     const int r_first = t0 - LEAD;             // first fed row
-    const int n_batches = (ye - ys + 4 + 7) / 8;
+    const int n_batches = (ye - ys + 2 * MH + 7) / 8;
+    const bool border_strip = strip_left || strip_right;
 
     uint32_t raw[8][3];
     Row ring[8];
+    RowBGR rawp[PRE_K == 3 ? 8 : 1];
+    // raw row in slot `sl` -> HSV row in ring[sl] (with PRE_K == 3: the HSV of the 3x3-blurred row before it)
+    auto convert = [&](int sl, bool have_rows) {
+        if (PRE_K == 3) {
+            unpack_row(raw[sl], rawp[sl & (PRE_K == 3 ? 7 : 0)]);
+            if (have_rows)
+                preblur_hsv_row<RGB>(rawp[(sl + 6) & (PRE_K == 3 ? 7 : 0)], rawp[(sl + 7) & (PRE_K == 3 ? 7 : 0)],
+                                     rawp[sl & (PRE_K == 3 ? 7 : 0)], border_strip, lb_halo, rb_halo, tab, ring[sl]);
+        } else {
+            hsv_row<RGB>(raw[sl], tab, ring[sl]);
+        }
+    };
     auto load_row = [&](int slot, int f) {
         const int r = reflect_row(r_first + f, h);
         const uint32_t off = (uint32_t)r * rs + lane_off;
@@ -263,12 +335,10 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     constexpr int S0 = (8 - 2 * LEAD) & 7;
 #pragma unroll
     for (int q = 0; q < PF; q++) load_row((S0 + q) & 7, q);
-    if (POST_K == 5) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            load_row((S0 + q + PF) & 7, q + PF);
-            hsv_row<RGB>(raw[(S0 + q) & 7], tab, ring[(S0 + q) & 7]);
-        }
+    for (int q = 0; q < 2 * LEAD; q++) {  // prologue: fill the rings
+        load_row((S0 + q + PF) & 7, q + PF);
+        convert((S0 + q) & 7, q >= (PRE_K == 3 ? 2 : 0));
     }
 
     uint32_t acc[NR], prev1[NR], prev2[NR];
@@ -286,7 +356,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
         for (int rr = 0; rr < 8; rr++) {
             const int f = 2 * LEAD + b * 8 + rr;  // fed index of this step's newest row
             load_row((rr + PF) & 7, f + PF);
-            hsv_row<RGB>(raw[rr], tab, ring[rr]);
+            convert(rr, true);
             uint32_t o_hs[4], o_v[2];
             if (POST_K == 5) {
                 uint32_t c_hs[4], c_v[2];
@@ -298,7 +368,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
                 for (int k = 0; k < 2; k++)
                     c_v[k] = vert5(ring[(rr + 4) & 7].v[k], ring[(rr + 5) & 7].v[k], ring[(rr + 6) & 7].v[k],
                                    ring[(rr + 7) & 7].v[k], ring[rr].v[k]);
-                if (strip_left || strip_right) {
+                if (border_strip) {
                     // BORDER_REFLECT_101 at the image's left/right edge: give the halo lane next to the border
                     // lane the mirrored columns, so the DPP fetches below read col -1 = col 1, col -2 = col 2
                     // (and col w = col w-2, col w+1 = col w-3).  Those halo lanes never produce output.
@@ -343,8 +413,27 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
                 acc[r] = t;
             }
         }
-        // ---- one 4x8 tile per range is complete: morphology, store, moments ----
         const int yt = t0 + b * 8;  // image row of tile position 0 at the inRange stage
+        if (MODE == 1) {
+            // ---- front end only: the inRange rows go out as 0/255 bytes ----
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const uint32_t t = acc[r];
+                u8 *rowp = mptr + (size_t)r * plane + (size_t)yt * w;  // uniform
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    const int y = yt + p;
+                    if (y >= ys && y < ye && lane_out) {
+                        const int sh = 4 * (7 - p) - 2;
+                        const uint32_t idx = (sh >= 0 ? (t >> sh) : (t << 2)) & 0x3Cu;
+                        *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) =
+                            *reinterpret_cast<const uint32_t *>(tab + 2048 + idx);
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- one 4x8 tile per range is complete: morphology, store, moments ----
         const uint32_t inv1 = colinv | rows_outside(yt, 0, h);
         const uint32_t inv2 = colinv | rows_outside(yt - 1, 0, h);
         const uint32_t keep = lane_out ? ~rows_outside(yt - 2, ys, ye) : 0u;
@@ -400,6 +489,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
         }
     }
 
+    if (MODE == 1) return;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
         unsigned long long s0 = m00[r], s1 = m10[r], s2 = m01[r];
@@ -438,17 +528,26 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 // ---------------------------------------------------------------------------------------------
 // planning / launch
 // ---------------------------------------------------------------------------------------------
-bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const ipk::Taps &, const ipk::Taps &,
-                const ipk::Bounds &bounds, FusedPlan *out)
+static bool plan_common(const imgproc_pipeline &pipe, const ipk::Bounds &bounds, FusedPlan &p)
 {
-    if (pipe.pre_blur_k > 1) return false;
+    if (!(pipe.pre_blur_k <= 1 || pipe.pre_blur_k == 3)) return false;
     if (!(pipe.post_blur_k <= 1 || pipe.post_blur_k == 5)) return false;
-    if (pipe.n_morph > 2 || bounds.n < 1 || bounds.n > MAX_NR) return false;
-    FusedPlan p{};
+    if (bounds.n < 1 || bounds.n > MAX_NR) return false;
     p.bidx = pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0;
     p.bayer = pipe.encoding == IMGPROC_ENC_BAYER_RGGB8;
     p.second_order = pipe.second_order != 0;
+    p.pre_k = pipe.pre_blur_k == 3 ? 3 : 1;
     p.post_k = pipe.post_blur_k == 5 ? 5 : 1;
+    p.bounds = bounds;
+    return true;
+}
+
+bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const ipk::Taps &, const ipk::Taps &,
+                const ipk::Bounds &bounds, FusedPlan *out)
+{
+    FusedPlan p{};
+    if (!plan_common(pipe, bounds, p) || pipe.n_morph > 2) return false;
+    p.mode = 0;
     p.n_groups = pipe.n_morph;
     p.kind[0] = p.kind[1] = 2;
     for (int i = 0; i < pipe.n_morph; i++) {
@@ -456,7 +555,19 @@ bool plan_fused(const imgproc_pipeline &pipe, const ipk::Element *elems, const i
         if (!e.is_rect || e.kw != 3 || e.kh != 3 || e.ax != 1 || e.ay != 1) return false;
         p.kind[i] = pipe.morph[i].kind == IMGPROC_DILATE ? 1 : 0;
     }
-    p.bounds = bounds;
+    // one halo lane = 4 columns: blur reach (pre 1, post 2) + one column per 3x3 op must fit
+    const int reach = (p.pre_k == 3 ? 1 : 0) + (p.post_k == 5 ? 2 : 0) + pipe.n_morph;
+    if (reach > 4) return false;
+    *out = p;
+    return true;
+}
+
+bool plan_front(const imgproc_pipeline &pipe, const ipk::Bounds &bounds, FusedPlan *out)
+{
+    FusedPlan p{};
+    if (!plan_common(pipe, bounds, p)) return false;
+    p.mode = 1;
+    p.kind[0] = p.kind[1] = 2;
     *out = p;
     return true;
 }
@@ -524,20 +635,35 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     }
     const dim3 grid((a.total_items + 3) / 4), block(256);
     const bool rgb = plan.bidx == 2;
-#define LAUNCH3(PK, RGBV, NRV, M2V) hipLaunchKernelGGL((k_fused_chain<PK, RGBV, NRV, 3, M2V>), grid, block, 0, stream, a)
-#define LAUNCH(PK, RGBV, NRV)                          \
-    do {                                               \
-        if (plan.second_order) LAUNCH3(PK, RGBV, NRV, true); \
-        else LAUNCH3(PK, RGBV, NRV, false);            \
+#define LAUNCH5(PRE, PK, RGBV, NRV, M2V, MODEV) \
+    hipLaunchKernelGGL((k_fused_chain<PRE, PK, RGBV, NRV, 3, M2V, MODEV>), grid, block, 0, stream, a)
+#define LAUNCH_M(PRE, PK, RGBV, NRV)                                        \
+    do {                                                                    \
+        if (plan.mode == 1) LAUNCH5(PRE, PK, RGBV, NRV, false, 1);          \
+        else if (plan.second_order) LAUNCH5(PRE, PK, RGBV, NRV, true, 0);   \
+        else LAUNCH5(PRE, PK, RGBV, NRV, false, 0);                         \
     } while (0)
-    if (plan.post_k == 5) {
-        if (nr == 1) { if (rgb) LAUNCH(5, true, 1); else LAUNCH(5, false, 1); }
-        else         { if (rgb) LAUNCH(5, true, 2); else LAUNCH(5, false, 2); }
+#define LAUNCH_N(PRE, PK, RGBV)                 \
+    do {                                        \
+        if (nr == 1) LAUNCH_M(PRE, PK, RGBV, 1); \
+        else LAUNCH_M(PRE, PK, RGBV, 2);        \
+    } while (0)
+#define LAUNCH_R(PRE, PK)                   \
+    do {                                    \
+        if (rgb) LAUNCH_N(PRE, PK, true);   \
+        else LAUNCH_N(PRE, PK, false);      \
+    } while (0)
+    if (plan.pre_k == 3) {
+        if (plan.post_k == 5) LAUNCH_R(3, 5);
+        else LAUNCH_R(3, 1);
     } else {
-        if (nr == 1) { if (rgb) LAUNCH(1, true, 1); else LAUNCH(1, false, 1); }
-        else         { if (rgb) LAUNCH(1, true, 2); else LAUNCH(1, false, 2); }
+        if (plan.post_k == 5) LAUNCH_R(1, 5);
+        else LAUNCH_R(1, 1);
     }
-#undef LAUNCH3
+#undef LAUNCH_R
+#undef LAUNCH_N
+#undef LAUNCH_M
+#undef LAUNCH5
 #undef LAUNCH
     return hipGetLastError();
 }

@@ -117,6 +117,12 @@ class ImgProc:
     def is_fused(self) -> bool:
         return bool(self.lib.imgproc_pipeline_is_fused(self._ctx))
 
+    @property
+    def plan(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._chk(self.lib.imgproc_pipeline_plan(self._ctx, buf, 256), "imgproc_pipeline_plan")
+        return buf.value.decode()
+
     # -- streaming ---------------------------------------------------------------------------
     def submit(self, slot: int, frame: np.ndarray):
         if frame.dtype != np.uint8 or frame.strides[-1] != 1 or (frame.ndim == 3 and frame.strides[1] != 3):

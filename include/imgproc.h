@@ -191,6 +191,8 @@ int imgproc_set_profiling(imgproc_ctx *ctx, int on);
 int imgproc_last_kernel_ms(imgproc_ctx *ctx, float *ms, int *launches);
 /* 1 if the current pipeline runs as one fused kernel, 0 if stage-by-stage */
 int imgproc_pipeline_is_fused(const imgproc_ctx *ctx);
+/* human-readable description of how the current pipeline will run (which kernels), for logs and tests */
+int imgproc_pipeline_plan(const imgproc_ctx *ctx, char *buf, size_t len);
 int imgproc_synchronize(imgproc_ctx *ctx);
 
 #ifdef __cplusplus

@@ -291,3 +291,40 @@ def test_fused_second_order_moments(gpu, oracle, name, hw):
         if m[0]:
             mu20, mu02, mu11 = m[3] - m[1] * m[1] / m[0], m[5] - m[2] * m[2] / m[0], m[4] - m[1] * m[2] / m[0]
             assert abs(res[r]["theta"] - 0.5 * np.arctan2(2 * mu11, mu20 - mu02)) < 1e-9
+
+
+def test_plans(gpu):
+    """Which kernels each reference chain runs on (imgproc_pipeline_plan)."""
+    gpu.set_ranges([DEFAULT_RANGE])
+    expect = {"pose_estimate": "fused chain kernel", "baseline": "fused chain kernel", "c1": "fused chain kernel",
+              "pose_estimate_full": "front kernel + bit-plane morphology (3 groups)",
+              "polygon_path": "front kernel + bit-plane morphology (5 groups)"}
+    for name, want in expect.items():
+        gpu.set_pipeline(**PRESETS[name])
+        assert gpu.plan == want, (name, gpu.plan)
+    gpu.set_pipeline(pre_blur_k=3, post_blur_k=5, morph=[ip.E(3)])
+    assert gpu.plan == "fused chain kernel"  # reach 1 + 2 + 1 = 4 columns: fits the halo lane
+    gpu.set_pipeline(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_BASELINE)
+    assert gpu.plan.startswith("front kernel")
+    gpu.set_pipeline(post_blur_k=15, morph=[ip.E(9, L.ELLIPSE)])
+    assert gpu.plan == "stage kernels + bit-plane morphology (1 groups)"
+    gpu.set_pipeline(keep_stages=True, **PRESETS["polygon_path"])
+    assert gpu.plan.startswith("stage kernels")
+    gpu.set_pipeline(force_unfused=True, **PRESETS["polygon_path"])
+    assert gpu.plan.startswith("stage kernels")
+
+
+@pytest.mark.parametrize("pre,post,morph", [(3, 5, [ip.E(3)]), (3, 0, ip.MORPH_BASELINE), (3, 0, []), (3, 5, []),
+                                            (3, 5, ip.MORPH_POSE_ESTIMATE), (0, 0, ip.MORPH_POLYGON_PATH)])
+@pytest.mark.parametrize("hw", [(37, 64), (123, 516), (480, 640)])
+def test_preblur_and_front_back_variants(gpu, oracle, pre, post, morph, hw):
+    f = synth_frame(hw[1], hw[0], 31)
+    ranges = [DEFAULT_RANGE, ((0, 0, 0), (90, 256, 256))]
+    gpu.set_pipeline(pre_blur_k=pre, post_blur_k=post, morph=morph, second_order=True)
+    gpu.set_ranges(ranges)
+    assert not gpu.plan.startswith("stage kernels")
+    res = gpu.process(f)
+    exp = oracle.chain(f, pre_blur_k=pre, post_blur_k=post, morph=morph_tuples(morph), ranges=ranges, stages=False)
+    for r in range(2):
+        assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all()
+        check_moments(res[r], exp["moments"][r], second=True)
