@@ -152,6 +152,13 @@ def main() -> None:
         k_ms = float(np.mean([m for m, _ in kernel_ms]))
         launches = kernel_ms[-1][1]
         achieved = BATCH * ALGO_BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
+        # --pmc runs of this same command, gfx950 x2 correction on the read side); null when the file is absent
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+        if fused and os.path.exists(tpath):
+            with open(tpath) as tf:
+                traffic = json.load(tf).get("hbm_bytes_per_launch")
         out = {
             "metric": "frames/sec at 1920x1200 BGR8, full chain (5x5 Gaussian, HSV inRange, 3x3 erode+dilate, moments)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -164,8 +171,8 @@ def main() -> None:
                        "sharding": f"frames x{world} ranks, no collective; {BATCH * world} centroids gathered on rank 0 "
                                    f"after the timed region ({n_found} with an object)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "ipf::k_fused_chain" if fused else "all stage kernels of one step",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "ipf::k_fused_chain<1,5,false,1,3,false,0>" if fused else "all stage kernels of one step",
                          "kernel_ms_per_launch": k_ms, "algorithmic_bytes_per_launch": BATCH * ALGO_BYTES_PER_FRAME},
             "achieved_gbps_whole_job": fps * ALGO_BYTES_PER_FRAME / 1e9,
         }
