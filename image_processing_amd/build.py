@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libimgproc_hip.so")
-SOURCES = ["api.hip", "kernels.hip", "fused.hip", "morphbits.hip"]
+SOURCES = ["api.hip", "kernels.hip", "fused.hip", "morphbits.hip", "gauss.hip"]
 HEADERS = ["kernels.h", "fused.h", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
 

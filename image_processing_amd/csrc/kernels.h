@@ -31,6 +31,10 @@ hipError_t launch_bgr2hsv(const u8 *src, size_t sstride, u8 *dst, size_t dstride
                           const int *d_tables, hipStream_t stream);
 hipError_t launch_gaussian(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int cn,
                            const Taps &taps, hipStream_t stream);
+// strip kernel (gauss.hip): odd k <= 15, symmetric taps summing to 256, 4-byte aligned source rows
+bool gaussian_strip_ok(const u8 *src, size_t sstride, int w, int h, int cn, const Taps &taps);
+hipError_t launch_gaussian_strip(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int cn,
+                                 const Taps &taps, hipStream_t stream);
 // dst plane r at dst + r*plane_stride
 hipError_t launch_in_range(const u8 *src, size_t sstride, u8 *dst, size_t dstride, size_t plane_stride, int w,
                            int h, const Bounds &b, hipStream_t stream);

@@ -135,6 +135,9 @@ hipError_t launch_gaussian(const u8 *src, size_t sstride, u8 *dst, size_t dstrid
 {
     if (w <= 0 || h <= 0) return hipSuccess;
     if ((cn != 1 && cn != 3) || taps.k < 1 || taps.k > 31 || !(taps.k & 1)) return hipErrorInvalidValue;
+    static const bool generic_only = getenv("IMGPROC_GAUSS_GENERIC") != nullptr;  // test hook: tile kernel only
+    if (!generic_only && gaussian_strip_ok(src, sstride, w, h, cn, taps))
+        return launch_gaussian_strip(src, sstride, dst, dstride, w, h, cn, taps, stream);
     dim3 grid((w * cn + G_TWB - 1) / G_TWB, (h + G_TH - 1) / G_TH);
     if (cn == 3)
         hipLaunchKernelGGL(k_gaussian<3>, grid, dim3(256), 0, stream, src, sstride, dst, dstride, w, h, taps);

@@ -9,7 +9,7 @@ from image_processing_amd.synth import synth_bayer_rggb, synth_frame
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(1, 1), (1, 13), (13, 1), (17, 13), (16, 64), (37, 250), (64, 256), (123, 517), (480, 640)]
+SHAPES = [(1, 1), (1, 13), (13, 1), (17, 13), (16, 64), (37, 250), (64, 256), (123, 517), (480, 640), (150, 1000)]
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +35,7 @@ def test_bgr2hsv_all_colours_lattice(gpu, oracle, kat):
 
 
 @pytest.mark.parametrize("hw", SHAPES)
-@pytest.mark.parametrize("k", [3, 5, 7, 15])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11, 13, 15, 21, 31])
 def test_gaussian(gpu, oracle, hw, k):
     rng = np.random.default_rng(hw[0] * 31 + hw[1] + k)
     img3 = rng.integers(0, 256, hw + (3,), dtype=np.uint8)
