@@ -494,9 +494,9 @@ IMGPROC_API int imgproc_pipeline_plan(const imgproc_ctx *c, char *buf, size_t le
     if (!c || !buf || !len) return IMGPROC_EINVAL;
     const Plan &p = c->plan;
     if (p.fused_ok)
-        snprintf(buf, len, "%sfused chain kernel", p.fused.bayer ? "demosaic + " : "");
+        snprintf(buf, len, "fused chain kernel%s", p.fused.bayer ? " (Bayer front end inside)" : "");
     else if (p.front_ok && p.bm_ok)
-        snprintf(buf, len, "%sfront kernel + bit-plane morphology (%d groups)", p.front.bayer ? "demosaic + " : "", (int)p.bm.groups.size());
+        snprintf(buf, len, "front kernel%s + bit-plane morphology (%d groups)", p.front.bayer ? " (Bayer front end inside)" : "", (int)p.bm.groups.size());
     else if (p.bm_ok)
         snprintf(buf, len, "stage kernels + bit-plane morphology (%d groups)", (int)p.bm.groups.size());
     else
@@ -531,21 +531,12 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
         HIPCHK(c, hipMemcpyAsync(s.d_raw, s.h_in, rowb * h, hipMemcpyHostToDevice, st));
         const int nr = p.bounds.n;
         HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, st));
-        if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, (size_t)w * 3, w, h, s.d_mask)) {
-            const u8 *src = s.d_raw;
-            if (p.fused.bayer) {  // Bayer front-end: demosaic to BGR (stage kernel), then the fused chain
-                HIPCHK(c, ipk::launch_demosaic_rggb(s.d_raw, rowb, s.d_bgr, (size_t)w * 3, w, h, st));
-                src = s.d_bgr;
-            }
-            HIPCHK(c, ipf::launch_fused(p.fused, src, 0, (size_t)w * 3, w, h, 1, s.d_mask, s.d_mom, c->d_tables, st));
-        } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, s.d_raw, 0, (size_t)w * 3, w, h, s.d_thresh)) {
-            // front kernel ([blur3] HSV [blur5] inRange -> bytes) + bit-plane back end (morph list, moments, mask)
-            const u8 *src = s.d_raw;
-            if (p.front.bayer) {
-                HIPCHK(c, ipk::launch_demosaic_rggb(s.d_raw, rowb, s.d_bgr, (size_t)w * 3, w, h, st));
-                src = s.d_bgr;
-            }
-            HIPCHK(c, ipf::launch_fused(p.front, src, 0, (size_t)w * 3, w, h, 1, s.d_thresh, nullptr, c->d_tables, st));
+        if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask)) {
+            // BGR8 / RGB8 / BayerRG8 all go straight into the chain kernel (the Bayer front end is part of it)
+            HIPCHK(c, ipf::launch_fused(p.fused, s.d_raw, 0, rowb, w, h, 1, s.d_mask, s.d_mom, c->d_tables, st));
+        } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, s.d_raw, 0, rowb, w, h, s.d_thresh)) {
+            // front kernel ([demosaic] [blur3] HSV [blur5] inRange -> bytes) + bit-plane back end (morph list, moments, mask)
+            HIPCHK(c, ipf::launch_fused(p.front, s.d_raw, 0, rowb, w, h, 1, s.d_thresh, nullptr, c->d_tables, st));
             HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, s.d_mask, s.d_mom, w, h, nr, p.pipe.second_order, st));
         } else {
             int rc2 = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr, st);
@@ -559,7 +550,7 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     // Measured on MI355X (scripts/stream_bench.py, 1920x1200, 3 slots): replaying the captured graph is SLOWER than
     // direct launches both for the fused chain (3.8 k vs 4.3 k frames/s) and for polygon_path's 23-launch chain (2.2 k vs
     // 3.1 k frames/s), so direct launches are the default and the graph path stays selectable.
-    const bool fused_now = p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, (size_t)w * 3, w, h, s.d_mask);
+    const bool fused_now = p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask);
     if (c->graph_mode == 1 || (c->graph_mode == 2 && !fused_now)) {
         if (!s.graph_exec || s.graph_w != w || s.graph_h != h || s.graph_epoch != c->plan_epoch) {
             if (s.graph_exec) {
@@ -688,13 +679,11 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
     c->prof_valid = false;
     c->prof_launches = 0;
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_k0, c->stream));
-    if (p.fused_ok && !p.fused.bayer && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
+    if (p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
         HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks,
                                     c->d_mom_batch, c->d_tables, c->stream));
         c->prof_launches = 1;
-    } else if (p.front_ok && p.bm_ok &&
-               ipf::can_launch_fused(p.front, p.front.bayer ? (const void *)s.d_bgr : d_frames, p.front.bayer ? 0 : frame_stride,
-                                     p.front.bayer ? (size_t)w * 3 : row_stride, w, h, d_masks)) {
+    } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks)) {
         const size_t need = (size_t)n * nr * px;
         if (need > c->thresh_batch_bytes) {  // grown on demand, kept for the life of the context
             if (c->d_thresh_batch) HIPCHK(c, hipFree(c->d_thresh_batch));
@@ -703,31 +692,11 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
             HIPCHK(c, hipMalloc((void **)&c->d_thresh_batch, need));
             c->thresh_batch_bytes = need;
         }
-        if (p.front.bayer) {
-            for (int i = 0; i < n; i++) {
-                HIPCHK(c, ipk::launch_demosaic_rggb((const u8 *)d_frames + (size_t)i * frame_stride, row_stride, s.d_bgr,
-                                                    (size_t)w * 3, w, h, c->stream));
-                HIPCHK(c, ipf::launch_fused(p.front, s.d_bgr, 0, (size_t)w * 3, w, h, 1, c->d_thresh_batch + (size_t)i * nr * px,
-                                            nullptr, c->d_tables, c->stream));
-                c->prof_launches += 2;
-            }
-        } else {
-            HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, c->d_thresh_batch,
-                                        nullptr, c->d_tables, c->stream));
-            c->prof_launches += 1;
-        }
+        HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, c->d_thresh_batch,
+                                    nullptr, c->d_tables, c->stream));
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, c->d_thresh_batch, (u8 *)d_masks, c->d_mom_batch, w, h, n * nr,
                                        p.pipe.second_order, c->stream));
-        c->prof_launches += 1;
-    } else if (p.fused_ok && p.fused.bayer && ipf::can_launch_fused(p.fused, s.d_bgr, 0, (size_t)w * 3, w, h, d_masks)) {
-        for (int i = 0; i < n; i++) {  // demosaic + fused chain per frame (two launches per frame)
-            HIPCHK(c, ipk::launch_demosaic_rggb((const u8 *)d_frames + (size_t)i * frame_stride, row_stride, s.d_bgr,
-                                                (size_t)w * 3, w, h, c->stream));
-            u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : nullptr;
-            HIPCHK(c, ipf::launch_fused(p.fused, s.d_bgr, 0, (size_t)w * 3, w, h, 1, mout, c->d_mom_batch + (size_t)i * nr * 6,
-                                        c->d_tables, c->stream));
-            c->prof_launches += 2;
-        }
+        c->prof_launches = 2;
     } else {
         for (int i = 0; i < n; i++) {
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;

@@ -10,7 +10,7 @@ struct FusedPlan {
     int variant;      // kernel specialisation chosen by plan_fused
     int bidx;         // 0 BGR input, 2 RGB input
     int second_order; // also accumulate m20/m11/m02
-    int bayer;        // input is BayerRG8: the caller demosaics to BGR first (k_demosaic_rggb), then this kernel runs
+    int bayer;        // input is BayerRG8 (1 B/px): the kernel demosaics while loading (two halo lanes per side)
     int pre_k;        // pre-HSV blur ksize on the raw channels (1 = none, 3)
     int post_k;       // post-HSV blur ksize (1 = none)
     int mode;         // 0: whole chain in the kernel; 1: front end only (inRange bytes out; morphbits.hip finishes)

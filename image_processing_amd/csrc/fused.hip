@@ -26,7 +26,8 @@ namespace ipf {
 
 using ipk::u8;
 
-constexpr int STRIP_VALID = 248;  // valid output columns per wave (lanes 1..62)
+constexpr int strip_valid(bool bayer) { return bayer ? 240 : 248; }  // valid output columns per wave: lanes 1..62, or
+                                                                     // 2..61 when the Bayer front end adds a column of reach
 constexpr int MAX_NR = 2;
 
 struct Args {
@@ -211,6 +212,75 @@ __device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &
     o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
 }
 
+// BayerRG8 front end (cv_bridge's bayer_rggb8 -> bgr8 == COLOR_BayerBG2BGR at pose_estimate.cpp:180):
+// bilinear demosaic of this lane's 4 pixels from the three mosaic rows y-1, y, y+1 (one dword each), SWAR on byte
+// pairs.  Index [0] holds pixels (0,2) = even columns, [1] holds pixels (1,3) = odd columns, as 16-bit fields.
+struct Pairs {
+    uint32_t b[2], g[2], r[2];
+};
+
+__device__ __forceinline__ void demosaic_row(const uint32_t (&w)[3], bool odd_row, bool border_strip, bool first_col,
+                                             bool last_col, Pairs &o)
+{
+    const uint32_t M8 = 0x00FF00FFu;
+    const uint32_t me = w[1] & M8, mo = (w[1] >> 8) & M8;                                          // centre row
+    const uint32_t vse = (w[0] & M8) + (w[2] & M8), vso = ((w[0] >> 8) & M8) + ((w[2] >> 8) & M8);  // up + down
+    const uint32_t hme = mo + alignbit(mo, from_left(mo), 16);   // left + right of the even columns: cols (-1,1) + (1,3)
+    const uint32_t hmo = me + alignbit(from_right(me), me, 16);  // left + right of the odd columns:  cols (0,2) + (2,4)
+    if (!odd_row) {  // R G R G: even columns are R sites, odd columns G with R left/right and B above/below
+        const uint32_t hve = vso + alignbit(vso, from_left(vso), 16);  // the four diagonals of the even columns
+        o.r[0] = me;
+        o.g[0] = ((hme + vse + 0x00020002u) >> 2) & M8;
+        o.b[0] = ((hve + 0x00020002u) >> 2) & M8;
+        o.g[1] = mo;
+        o.r[1] = ((hmo + 0x00010001u) >> 1) & M8;
+        o.b[1] = ((vso + 0x00010001u) >> 1) & M8;
+    } else {  // G B G B: odd columns are B sites, even columns G with B left/right and R above/below
+        const uint32_t hvo = vse + alignbit(from_right(vse), vse, 16);
+        o.g[0] = me;
+        o.b[0] = ((hme + 0x00010001u) >> 1) & M8;
+        o.r[0] = ((vse + 0x00010001u) >> 1) & M8;
+        o.b[1] = mo;
+        o.g[1] = ((hmo + vso + 0x00020002u) >> 2) & M8;
+        o.r[1] = ((hvo + 0x00020002u) >> 2) & M8;
+    }
+    if (border_strip) {  // OpenCV leaves no interpolated border: column 0 copies column 1, column w-1 copies w-2
+        if (first_col) {
+            o.b[0] = (o.b[0] & 0xFFFF0000u) | (o.b[1] & 0xFFFFu);
+            o.g[0] = (o.g[0] & 0xFFFF0000u) | (o.g[1] & 0xFFFFu);
+            o.r[0] = (o.r[0] & 0xFFFF0000u) | (o.r[1] & 0xFFFFu);
+        }
+        if (last_col) {
+            o.b[1] = (o.b[1] & 0xFFFFu) | (o.b[0] & 0xFFFF0000u);
+            o.g[1] = (o.g[1] & 0xFFFFu) | (o.g[0] & 0xFFFF0000u);
+            o.r[1] = (o.r[1] & 0xFFFFu) | (o.r[0] & 0xFFFF0000u);
+        }
+    }
+}
+
+__device__ __forceinline__ void hsv_row_pairs(const Pairs &p, const char *tab, Row &o)
+{
+    uint32_t vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = k & 1, sh = (k >> 1) * 16;
+        hsv_px<false>(((p.b[q] >> sh) & 0xFFFFu) << 2, ((p.g[q] >> sh) & 0xFFFFu) << 2, ((p.r[q] >> sh) & 0xFFFFu) << 2, tab,
+                      o.hs[k], vv[k]);
+    }
+    o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;
+    o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
+}
+
+__device__ __forceinline__ void pairs_to_row(const Pairs &p, RowBGR &o)
+{
+    o.c01[0] = __builtin_amdgcn_perm(p.g[0], p.b[0], 0x05040100u);
+    o.c01[1] = __builtin_amdgcn_perm(p.g[1], p.b[1], 0x05040100u);
+    o.c01[2] = __builtin_amdgcn_perm(p.g[0], p.b[0], 0x07060302u);
+    o.c01[3] = __builtin_amdgcn_perm(p.g[1], p.b[1], 0x07060302u);
+    o.c2[0] = __builtin_amdgcn_perm(p.r[1], p.r[0], 0x05040100u);
+    o.c2[1] = __builtin_amdgcn_perm(p.r[1], p.r[0], 0x07060302u);
+}
+
 // vertical 1-4-6-4-1 on packed fields, +8 per field (the folded rounding)
 __device__ __forceinline__ uint32_t vert5(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4)
 {
@@ -265,7 +335,8 @@ __device__ __forceinline__ uint32_t rows_outside(int y0, int lo, int hi)  // nib
 
 // MODE 0: whole chain (up to two 3x3 ops, moments, final mask).  MODE 1: front end only: the inRange output is
 // written as 0/255 bytes to a.masks (the bit-plane back end, morphbits.hip, runs the morph list and the moments).
-template <int PRE_K, int POST_K, bool RGB, int NR, int PF, bool M2, int MODE>
+// BAYER: the frames are BayerRG8 mosaics (1 B/px); every fed row loads the three mosaic rows it is interpolated from.
+template <int PRE_K, int POST_K, bool RGB, int NR, int PF, bool M2, int MODE, bool BAYER>
 __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 {
     __shared__ int s_tab[512 + 16];
@@ -287,18 +358,21 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const int w = a.w, h = a.h;
     const int ys = seg * a.seg_rows;
     const int ye = min(ys + a.seg_rows, h);
-    const int x0 = strip * STRIP_VALID - 4 + lane * 4;
+    constexpr int HL = BAYER ? 2 : 1;  // halo lanes per side
+    constexpr int SV = strip_valid(BAYER);
+    const int x0 = strip * SV - 4 * HL + lane * 4;
     const int xl = min(max(x0, 0), w - 4);
     const bool in_image = x0 >= 0 && x0 < w;
-    const bool lane_out = in_image && lane >= 1 && lane <= 62;
+    const bool lane_out = in_image && lane >= HL && lane <= 63 - HL;
     const bool strip_left = strip == 0;
-    const bool strip_right = strip * STRIP_VALID + 252 >= w;
+    const bool strip_right = strip * SV + 256 - 4 * HL >= w;
     const bool lb_halo = x0 == -4, rb_halo = x0 == w;  // halo lanes just outside the left / right image border
     const uint32_t colinv = in_image ? 0u : 0xFFFFFFFFu;
 
     // uniform (SGPR) frame pointer + 32-bit per-lane byte offset: loads use the saddr form
     const u8 *fptr = a.frames + (size_t)frame * a.frame_stride;
-    const uint32_t lane_off = (uint32_t)xl * 3u;
+    const uint32_t lane_off = (uint32_t)xl * (BAYER ? 1u : 3u);
+    const bool first_col = x0 == 0, last_col = x0 == w - 4;  // Bayer: the image's border columns copy their neighbours
     const uint32_t rs = (uint32_t)a.row_stride;  // byte offsets inside one frame fit 32 bits (checked at launch)
 
     constexpr int LEAD = (POST_K == 5 ? 2 : 0) + (PRE_K == 3 ? 1 : 0);  // rows of look-ahead the blurs need
@@ -312,23 +386,38 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     Row ring[8];
     RowBGR rawp[PRE_K == 3 ? 8 : 1];
     // raw row in slot `sl` -> HSV row in ring[sl] (with PRE_K == 3: the HSV of the 3x3-blurred row before it)
-    auto convert = [&](int sl, bool have_rows) {
+    auto bayer_row = [&](int f) { return min(max(reflect_row(r_first + f, h), 1), h - 2); };  // border rows copy too
+    auto convert = [&](int sl, bool have_rows, int f) {
+        Pairs bp;
+        if (BAYER) demosaic_row(raw[sl], bayer_row(f) & 1, border_strip, first_col, last_col, bp);
         if (PRE_K == 3) {
-            unpack_row(raw[sl], rawp[sl & (PRE_K == 3 ? 7 : 0)]);
+            if (BAYER)
+                pairs_to_row(bp, rawp[sl & (PRE_K == 3 ? 7 : 0)]);
+            else
+                unpack_row(raw[sl], rawp[sl & (PRE_K == 3 ? 7 : 0)]);
             if (have_rows)
                 preblur_hsv_row<RGB>(rawp[(sl + 6) & (PRE_K == 3 ? 7 : 0)], rawp[(sl + 7) & (PRE_K == 3 ? 7 : 0)],
                                      rawp[sl & (PRE_K == 3 ? 7 : 0)], border_strip, lb_halo, rb_halo, tab, ring[sl]);
+        } else if (BAYER) {
+            hsv_row_pairs(bp, tab, ring[sl]);
         } else {
             hsv_row<RGB>(raw[sl], tab, ring[sl]);
         }
     };
     auto load_row = [&](int slot, int f) {
-        const int r = reflect_row(r_first + f, h);
-        const uint32_t off = (uint32_t)r * rs + lane_off;
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(fptr + off);
-        raw[slot][0] = p[0];
-        raw[slot][1] = p[1];
-        raw[slot][2] = p[2];
+        if (BAYER) {
+            const uint32_t off = (uint32_t)(bayer_row(f) - 1) * rs + lane_off;
+            raw[slot][0] = *reinterpret_cast<const uint32_t *>(fptr + off);
+            raw[slot][1] = *reinterpret_cast<const uint32_t *>(fptr + off + rs);
+            raw[slot][2] = *reinterpret_cast<const uint32_t *>(fptr + off + 2 * rs);
+        } else {
+            const int r = reflect_row(r_first + f, h);
+            const uint32_t off = (uint32_t)r * rs + lane_off;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(fptr + off);
+            raw[slot][0] = p[0];
+            raw[slot][1] = p[1];
+            raw[slot][2] = p[2];
+        }
     };
 
     // fed row f uses raw/ring slot (f + 8 - 2*LEAD) & 7, so that the main step j = f - 2*LEAD uses slot j & 7
@@ -338,7 +427,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 #pragma unroll
     for (int q = 0; q < 2 * LEAD; q++) {  // prologue: fill the rings
         load_row((S0 + q + PF) & 7, q + PF);
-        convert((S0 + q) & 7, q >= (PRE_K == 3 ? 2 : 0));
+        convert((S0 + q) & 7, q >= (PRE_K == 3 ? 2 : 0), q);
     }
 
     uint32_t acc[NR], prev1[NR], prev2[NR];
@@ -356,7 +445,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
         for (int rr = 0; rr < 8; rr++) {
             const int f = 2 * LEAD + b * 8 + rr;  // fed index of this step's newest row
             load_row((rr + PF) & 7, f + PF);
-            convert(rr, true);
+            convert(rr, true, f);
             uint32_t o_hs[4], o_v[2];
             if (POST_K == 5) {
                 uint32_t c_hs[4], c_v[2];
@@ -572,10 +661,11 @@ bool plan_front(const imgproc_pipeline &pipe, const ipk::Bounds &bounds, FusedPl
     return true;
 }
 
-bool can_launch_fused(const FusedPlan &, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
+bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
                       const void *d_masks)
 {
     if (w < 4 || (w & 3) || h < 1 || w > 16384 || h > 16384) return false;
+    if (plan.bayer && h < 3) return false;  // no interior row: OpenCV writes zeros, the stage kernel does that
     if ((unsigned long long)row_stride * (unsigned long long)h >= (1ull << 32)) return false;  // 32-bit in-frame offsets
     if (((uintptr_t)d_frames & 3) || (frame_stride & 3) || (row_stride & 3) || ((uintptr_t)d_masks & 3)) return false;
     return true;
@@ -609,7 +699,8 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
         a.seg_rows = 512;
         a.n_segs = (h + 511) / 512;
     }
-    a.n_strips = (w + STRIP_VALID - 1) / STRIP_VALID;
+    const int sv = strip_valid(plan.bayer != 0);
+    a.n_strips = (w + sv - 1) / sv;
     a.total_items = a.n_strips * a.n_segs * n;
     a.op0 = plan.kind[0];
     a.op1 = plan.kind[1];
@@ -636,7 +727,15 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     const dim3 grid((a.total_items + 3) / 4), block(256);
     const bool rgb = plan.bidx == 2;
 #define LAUNCH5(PRE, PK, RGBV, NRV, M2V, MODEV) \
-    hipLaunchKernelGGL((k_fused_chain<PRE, PK, RGBV, NRV, 3, M2V, MODEV>), grid, block, 0, stream, a)
+    hipLaunchKernelGGL((k_fused_chain<PRE, PK, RGBV, NRV, 3, M2V, MODEV, false>), grid, block, 0, stream, a)
+#define LAUNCH5B(PRE, PK, NRV, M2V, MODEV) \
+    hipLaunchKernelGGL((k_fused_chain<PRE, PK, false, NRV, 3, M2V, MODEV, true>), grid, block, 0, stream, a)
+#define LAUNCH_MB(PRE, PK, NRV)                                       \
+    do {                                                              \
+        if (plan.mode == 1) LAUNCH5B(PRE, PK, NRV, false, 1);         \
+        else if (plan.second_order) LAUNCH5B(PRE, PK, NRV, true, 0);  \
+        else LAUNCH5B(PRE, PK, NRV, false, 0);                        \
+    } while (0)
 #define LAUNCH_M(PRE, PK, RGBV, NRV)                                        \
     do {                                                                    \
         if (plan.mode == 1) LAUNCH5(PRE, PK, RGBV, NRV, false, 1);          \
@@ -648,10 +747,13 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
         if (nr == 1) LAUNCH_M(PRE, PK, RGBV, 1); \
         else LAUNCH_M(PRE, PK, RGBV, 2);        \
     } while (0)
-#define LAUNCH_R(PRE, PK)                   \
-    do {                                    \
-        if (rgb) LAUNCH_N(PRE, PK, true);   \
-        else LAUNCH_N(PRE, PK, false);      \
+#define LAUNCH_R(PRE, PK)                       \
+    do {                                        \
+        if (plan.bayer) {                       \
+            if (nr == 1) LAUNCH_MB(PRE, PK, 1); \
+            else LAUNCH_MB(PRE, PK, 2);         \
+        } else if (rgb) LAUNCH_N(PRE, PK, true); \
+        else LAUNCH_N(PRE, PK, false);          \
     } while (0)
     if (plan.pre_k == 3) {
         if (plan.post_k == 5) LAUNCH_R(3, 5);
@@ -664,6 +766,8 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
 #undef LAUNCH_N
 #undef LAUNCH_M
 #undef LAUNCH5
+#undef LAUNCH5B
+#undef LAUNCH_MB
 #undef LAUNCH
     return hipGetLastError();
 }

@@ -124,9 +124,34 @@ def test_bayer_chain(gpu, oracle):
     check_moments(res[0], exp["moments"][0])
 
 
+@pytest.mark.parametrize("hw", [(3, 4), (4, 8), (5, 236), (33, 240), (64, 244), (57, 484), (131, 1000)])
+@pytest.mark.parametrize("preset", ["pose_estimate", "baseline", "polygon_path"])
+def test_bayer_front_end_noise(gpu, oracle, hw, preset):
+    """The Bayer front end inside the chain / front kernels on full-range noise mosaics (every demosaiced value matters:
+    no blur in `pose_estimate`, two ranges, one of them narrow), sizes around the 240-column strip of the Bayer variant."""
+    h, w = hw
+    raw = np.random.default_rng(h * 7919 + w).integers(0, 256, (h, w), dtype=np.uint8)
+    ranges = [((0, 40, 60), (90, 256, 256)), ((85, 0, 100), (140, 200, 220))]
+    kw = PRESETS[preset]
+    gpu.set_pipeline(encoding=L.ENC_BAYER_RGGB8, second_order=True, **kw)
+    gpu.set_ranges(ranges)
+    assert "Bayer front end inside" in gpu.plan
+    res = gpu.process(raw)
+    exp = oracle.chain(raw, encoding=2, pre_blur_k=kw["pre_blur_k"], post_blur_k=kw["post_blur_k"],
+                       morph=morph_tuples(kw["morph"]), ranges=ranges, stages=False)
+    for r in range(2):
+        assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all(), (preset, hw, r)
+        check_moments(res[r], exp["moments"][r], second=True)
+    gpu.set_pipeline(encoding=L.ENC_BAYER_RGGB8, force_unfused=True, **kw)  # the demosaic stage kernel agrees
+    gpu.set_ranges(ranges)
+    gpu.process(raw)
+    for r in range(2):
+        assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all(), ("unfused", preset, hw, r)
+
+
 @pytest.mark.parametrize("hw", [(100, 256), (480, 640)])
 def test_bayer_chain_fused_backend(gpu, oracle, hw):
-    """BayerRG8 input with a fusable tail: demosaic kernel + fused chain (BASELINE config 3's operators)."""
+    """BayerRG8 input with a fusable tail: the chain kernel demosaics while loading (BASELINE config 3's operators)."""
     h, w = hw
     raws = np.stack([synth_bayer_rggb(w, h, i) for i in range(3)])
     gpu.set_pipeline(encoding=L.ENC_BAYER_RGGB8, post_blur_k=5, morph=ip.MORPH_BASELINE)

@@ -28,7 +28,7 @@ def test_config3_bayer_2448x2048(oracle):
     with ip.ImgProc(w, h, n_slots=2) as g:
         g.set_pipeline(encoding=L.ENC_BAYER_RGGB8, post_blur_k=5, morph=ip.MORPH_BASELINE)
         g.set_ranges([DEFAULT_RANGE])
-        assert g.plan == "demosaic + fused chain kernel"
+        assert g.plan == "fused chain kernel (Bayer front end inside)"
         res = g.process_batch(np.stack(raws))
         r0 = g.process(raws[0])
         m0 = g.fetch_stage(0, L.STAGE_MASK)
