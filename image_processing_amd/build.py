@@ -13,21 +13,41 @@ HEADERS = ["kernels.h", "fused.h", "morphbits.h", os.path.join("..", "..", "incl
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+OBJDIR = os.path.join(LIBDIR, "obj")
+
+
+def _newer(path: str, deps) -> bool:
+    """True when `path` is missing or older than any of `deps`."""
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    t = os.path.getmtime(path)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if force or _stale():
-        os.makedirs(LIBDIR, exist_ok=True)
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    """One hipcc -c per source (in parallel, only the stale ones), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [os.path.join(CSRC, src)] + headers):
+            jobs.append([hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("MAX_JOBS", "6")))) as ex:
+            list(ex.map(run, jobs))
+    if force or jobs or _newer(LIB, objs):
+        run([hipcc] + FLAGS + ["-o", LIB] + objs)
     build_node_sim(force)
     return LIB
 

@@ -36,6 +36,9 @@ struct Slot {
     bool in_flight = false, has_frame = false;
     const u8 *blur_ptr = nullptr, *hsv_ptr = nullptr, *bgr_ptr = nullptr;  // where each kept stage lives
     size_t bgr_stride = 0;
+    int valid_upto = -1;        // highest of IMGPROC_STAGE_BGR..THRESH that is materialised for the frame in the slot
+    int masked_range = -1;      // d_masked holds frame & mask of this range (-1: not built)
+    unsigned frame_epoch = 0;   // plan epoch the frame was submitted under
 };
 
 struct Plan {
@@ -234,8 +237,9 @@ int alloc_slot(imgproc_ctx *c, Slot &s)
 
 // Stage-by-stage chain for one frame whose raw bytes are at d_frame (device).  Final masks land in
 // d_masks_out (n_ranges planes of w*h, tight), moments are ADDED into d_mom (caller zeroes).
+// `upto` < IMGPROC_STAGE_MASK stops after that stage (imgproc_fetch_stage rebuilding a stage image on demand).
 int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, int w, int h, u8 *d_masks_out,
-                unsigned long long *d_mom, int *launches, hipStream_t st)
+                unsigned long long *d_mom, int *launches, hipStream_t st, int upto = IMGPROC_STAGE_MASK)
 {
     const Plan &p = c->plan;
     const size_t t3 = (size_t)w * 3, px = (size_t)w * h;
@@ -259,9 +263,11 @@ int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, i
     }
     s.bgr_ptr = cur;  // may be the caller's frame itself (then the row stride is the caller's)
     s.bgr_stride = cur_stride;
+    if (upto == IMGPROC_STAGE_BGR) return 0;
     HIPCHK(c, ipk::launch_bgr2hsv(cur, cur_stride, s.d_a, t3, w, h, bidx, c->d_tables, st));
     nl++;
     s.hsv_ptr = s.d_a;
+    if (upto == IMGPROC_STAGE_HSV) return 0;
     const u8 *blur = s.d_a;
     if (p.pipe.post_blur_k > 1) {
         HIPCHK(c, ipk::launch_gaussian(s.d_a, t3, s.d_b, t3, w, h, 3, p.post, st));
@@ -269,9 +275,11 @@ int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, i
         blur = s.d_b;
     }
     s.blur_ptr = blur;
+    if (upto == IMGPROC_STAGE_BLUR) return 0;
     const int nr = p.bounds.n;
     HIPCHK(c, ipk::launch_in_range(blur, t3, s.d_thresh, (size_t)w, px, w, h, p.bounds, st));
     nl++;
+    if (upto == IMGPROC_STAGE_THRESH) return 0;
     if (p.bm_ok && !p.pipe.force_unfused) {
         // whole morph list + moments + final masks for all ranges in one launch on bit planes
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, d_masks_out, d_mom, w, h, nr, p.pipe.second_order, st));
@@ -527,14 +535,17 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
         for (int y = 0; y < h; y++) memcpy(s.h_in + (size_t)y * rowb, data + (size_t)y * stride, rowb);
     // The per-frame work {H2D, memset, chain kernels, D2H of the moments} has fixed pointers and sizes for a given
     // (slot, w, h, plan): it is captured once into a hipGraph and replayed with one hipGraphLaunch per frame.
+    // 0: chain kernel, 1: front kernel + bit-plane back end, 2: stage by stage
+    const int path = (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask)) ? 0
+                     : (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, s.d_raw, 0, rowb, w, h, s.d_thresh)) ? 1 : 2;
     auto enqueue = [&](hipStream_t st) -> int {
         HIPCHK(c, hipMemcpyAsync(s.d_raw, s.h_in, rowb * h, hipMemcpyHostToDevice, st));
         const int nr = p.bounds.n;
         HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, st));
-        if (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask)) {
+        if (path == 0) {
             // BGR8 / RGB8 / BayerRG8 all go straight into the chain kernel (the Bayer front end is part of it)
             HIPCHK(c, ipf::launch_fused(p.fused, s.d_raw, 0, rowb, w, h, 1, s.d_mask, s.d_mom, c->d_tables, st));
-        } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, s.d_raw, 0, rowb, w, h, s.d_thresh)) {
+        } else if (path == 1) {
             // front kernel ([demosaic] [blur3] HSV [blur5] inRange -> bytes) + bit-plane back end (morph list, moments, mask)
             HIPCHK(c, ipf::launch_fused(p.front, s.d_raw, 0, rowb, w, h, 1, s.d_thresh, nullptr, c->d_tables, st));
             HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, s.d_mask, s.d_mom, w, h, nr, p.pipe.second_order, st));
@@ -550,7 +561,7 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     // Measured on MI355X (scripts/stream_bench.py, 1920x1200, 3 slots): replaying the captured graph is SLOWER than
     // direct launches both for the fused chain (3.8 k vs 4.3 k frames/s) and for polygon_path's 23-launch chain (2.2 k vs
     // 3.1 k frames/s), so direct launches are the default and the graph path stays selectable.
-    const bool fused_now = p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask);
+    const bool fused_now = path == 0;
     if (c->graph_mode == 1 || (c->graph_mode == 2 && !fused_now)) {
         if (!s.graph_exec || s.graph_w != w || s.graph_h != h || s.graph_epoch != c->plan_epoch) {
             if (s.graph_exec) {
@@ -583,6 +594,9 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     s.h = h;
     s.in_flight = true;
     s.has_frame = true;
+    s.frame_epoch = c->plan_epoch;
+    s.valid_upto = path == 2 ? IMGPROC_STAGE_THRESH : -1;  // the fast paths leave no colour stage behind
+    s.masked_range = (path == 2 && p.pipe.keep_stages) ? 0 : -1;
     return IMGPROC_OK;
 }
 
@@ -608,11 +622,31 @@ IMGPROC_API int imgproc_fetch_stage(imgproc_ctx *c, int slot, int stage, int ran
     Slot &s = c->slots[slot];
     if (!s.has_frame) return fail(c, IMGPROC_ESTATE, "slot %d holds no frame", slot);
     if (range < 0 || range >= c->plan.bounds.n) return fail(c, IMGPROC_EINVAL, "range %d", range);
-    const bool keep = c->plan.pipe.keep_stages != 0;
-    if (stage != IMGPROC_STAGE_MASK && !keep)
-        return fail(c, IMGPROC_ESTATE, "stage %d needs pipeline.keep_stages", stage);
+    if (stage < IMGPROC_STAGE_BGR || stage > IMGPROC_STAGE_MASKED) return fail(c, IMGPROC_EINVAL, "stage %d", stage);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (s.in_flight) HIPCHK(c, hipEventSynchronize(s.ev_done));
+    // The fast paths (chain kernel, front kernel + bit planes) leave only the final mask behind.  Any other stage image
+    // is rebuilt here, on demand, from the raw frame that is still in the slot, with the stage kernels -- bit-identical
+    // to what the fast path computed internally (tests/test_gpu_chain.py), paid for only by callers that ask.
+    // keep_stages != 0 produces them all at submit instead.
+    const int need = stage == IMGPROC_STAGE_MASK ? -1 : stage == IMGPROC_STAGE_MASKED ? IMGPROC_STAGE_BGR : stage;
+    const bool rebuild = need > s.valid_upto || (stage == IMGPROC_STAGE_MASKED && s.masked_range != range);
+    if (rebuild) {
+        if (s.frame_epoch != c->plan_epoch)
+            return fail(c, IMGPROC_ESTATE, "stage %d: pipeline or ranges changed since the frame in slot %d was submitted", stage, slot);
+        const size_t rawb = (size_t)s.w * (c->plan.pipe.encoding == IMGPROC_ENC_BAYER_RGGB8 ? 1 : 3);
+        if (need > s.valid_upto) {
+            int rc = run_unfused(c, s, s.d_raw, rawb, s.w, s.h, nullptr, nullptr, nullptr, s.stream, need);
+            if (rc) return rc;
+            s.valid_upto = need;
+        }
+        if (stage == IMGPROC_STAGE_MASKED && s.masked_range != range) {
+            HIPCHK(c, ipk::launch_mask_and(s.bgr_ptr, s.bgr_stride, s.d_mask + (size_t)s.w * s.h * range, (size_t)s.w, s.d_masked,
+                                           (size_t)s.w * 3, s.w, s.h, s.stream));
+            s.masked_range = range;
+        }
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+    }
     const size_t px = (size_t)s.w * s.h;
     const u8 *src = nullptr;
     size_t rowb = 0, src_stride = 0;

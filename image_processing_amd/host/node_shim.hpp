@@ -161,7 +161,7 @@ public:
             p.morph[i].kw = p.morph[i].kh = seq[i] ? 8 : 3;
             p.morph[i].anchor_x = p.morph[i].anchor_y = -1;
         }
-        p.keep_stages = 1;
+        p.keep_stages = 0;  // fast path (front kernel + bit planes); procFrame is rebuilt on demand by fetch_stage
         check(ctx_, imgproc_set_pipeline(ctx_, &p), "imgproc_set_pipeline");
     }
     ~PolygonPathShim() { imgproc_destroy(ctx_); }

@@ -57,7 +57,8 @@ enum imgproc_morph_kind { IMGPROC_ERODE = 0, IMGPROC_DILATE = 1 };
  * (objectPolygonPath.cpp:31-32, pose_estimate.cpp:40-41) */
 enum imgproc_shape { IMGPROC_RECT = 0, IMGPROC_CROSS = 1, IMGPROC_ELLIPSE = 2, IMGPROC_CUSTOM = 3 };
 
-/* stage outputs that imgproc_fetch_stage can return (needs pipeline.keep_stages != 0) */
+/* stage outputs that imgproc_fetch_stage can return (MASK always; the others are kept at submit when
+ * pipeline.keep_stages != 0, otherwise rebuilt from the slot's raw frame when they are asked for) */
 enum imgproc_stage {
     IMGPROC_STAGE_BGR = 0,    /* u8x3: after demosaic / channel order normalisation / pre-blur   */
     IMGPROC_STAGE_HSV = 1,    /* u8x3: cvtColor BGR2HSV output                                   */
@@ -96,7 +97,8 @@ typedef struct imgproc_pipeline {
     int post_blur_k;
     int n_morph;
     imgproc_morph morph[IMGPROC_MAX_MORPH];
-    int keep_stages;   /* keep every stage output on the device for imgproc_fetch_stage */
+    int keep_stages;   /* produce and keep every stage output at submit (stage-by-stage path); 0: fast path, stage
+                          images other than MASK are rebuilt on demand inside imgproc_fetch_stage */
     int force_unfused; /* run stage-by-stage kernels even when a fused kernel exists (parity tests) */
     int second_order;  /* also compute m20/m11/m02 and theta; 0: they are reported as 0 */
 } imgproc_pipeline;

@@ -124,6 +124,42 @@ def test_bayer_chain(gpu, oracle):
     check_moments(res[0], exp["moments"][0])
 
 
+@pytest.mark.parametrize("preset", ["baseline", "polygon_path"])
+@pytest.mark.parametrize("enc", ["bgr", "bayer"])
+def test_fetch_stage_on_demand(gpu, oracle, preset, enc):
+    """keep_stages = 0 (the fast paths): every stage image can still be fetched; it is rebuilt from the slot's raw frame
+    and equals the oracle's stage, which pins the fast path's internal stages too (its mask / moments match the same
+    oracle run).  MASKED is frame & mask (objectPolygonPath.cpp:189-190) for the range asked for."""
+    h, w = 96, 256
+    kw = PRESETS[preset]
+    ranges = [DEFAULT_RANGE, ((0, 0, 0), (90, 256, 120))]
+    frame = synth_bayer_rggb(w, h, 5) if enc == "bayer" else synth_frame(w, h, 5)
+    encoding = L.ENC_BAYER_RGGB8 if enc == "bayer" else L.ENC_BGR8
+    gpu.set_pipeline(encoding=encoding, **kw)
+    gpu.set_ranges(ranges)
+    assert "stage kernels" not in gpu.plan
+    res = gpu.process(frame)
+    exp = oracle.chain(frame, encoding=2 if enc == "bayer" else 0, pre_blur_k=kw["pre_blur_k"], post_blur_k=kw["post_blur_k"],
+                       morph=morph_tuples(kw["morph"]), ranges=ranges, stages=True)
+    for r in (1, 0):
+        masked = gpu.fetch_stage(0, L.STAGE_MASKED, r)
+        assert (masked == (exp["bgr"] & exp["mask"][r][:, :, None])).all()
+        assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all()
+        check_moments(res[r], exp["moments"][r])
+    assert (gpu.fetch_stage(0, L.STAGE_THRESH, 1) == exp["thresh"][1]).all()
+    assert (gpu.fetch_stage(0, L.STAGE_BLUR) == exp["blur"]).all()
+    assert (gpu.fetch_stage(0, L.STAGE_HSV) == exp["hsv"]).all()
+    assert (gpu.fetch_stage(0, L.STAGE_BGR) == exp["bgr"]).all()
+    gpu.set_ranges([DEFAULT_RANGE])  # parameters changed: the old frame's stages can no longer be rebuilt
+    frame2 = synth_bayer_rggb(w, h, 6) if enc == "bayer" else synth_frame(w, h, 6)
+    gpu.process(frame2)
+    assert gpu.fetch_stage(0, L.STAGE_HSV).shape == (h, w, 3)
+    gpu.set_ranges(ranges)
+    with pytest.raises(ip.ImgProcError):
+        gpu.fetch_stage(0, L.STAGE_BLUR)
+    assert gpu.fetch_stage(0, L.STAGE_HSV).shape == (h, w, 3)  # already materialised: still served
+
+
 @pytest.mark.parametrize("hw", [(3, 4), (4, 8), (5, 236), (33, 240), (64, 244), (57, 484), (131, 1000)])
 @pytest.mark.parametrize("preset", ["pose_estimate", "baseline", "polygon_path"])
 def test_bayer_front_end_noise(gpu, oracle, hw, preset):
