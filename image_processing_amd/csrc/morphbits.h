@@ -7,11 +7,20 @@
 
 namespace ipm {
 
-struct Group {      // one (possibly merged) erode/dilate
-    int kind;       // 0 erode, 1 dilate
-    int nrows, ay;  // element rows and anchor row (a merged RECT group may be taller than 31)
-    int rect;       // all rows share the span lx[0]..hx[0]: runs separably
-    int8_t lx[32], hx[32];  // per element row: x offsets of its span relative to the anchor (lx > hx: empty row)
+constexpr int MAX_SPANS = 16;
+
+struct Span {          // the element rows that share one horizontal span
+    int8_t lx, hx;     // x offsets of the span relative to the anchor
+    int16_t dy_lo, dy_hi;  // first / last row offset (relative to the anchor row) that uses it
+    uint32_t rows;     // bit (dy - dy_lo): the element row at dy uses this span; 0 = every row of dy_lo..dy_hi (merged RECT)
+};
+
+struct Group {         // one (possibly merged) erode/dilate, in the form the kernel walks
+    int kind;          // 0 erode, 1 dilate
+    int n_spans;
+    int t_in, b_in;    // tile rows at the top / bottom that are already invalid before this group (reach of earlier groups)
+    int t_out, b_out;  // ... and after it
+    Span spans[MAX_SPANS];
 };
 
 struct Plan {

@@ -71,10 +71,14 @@ __device__ __forceinline__ uint32_t window_and(uint32_t p, uint32_t c, uint32_t 
     return s ? ((a0 >> s) | (a1 << (32 - s))) : a0;
 }
 
+constexpr int N_WORDS_MAX = LH_MAX * LW_MAX;
+constexpr int WORDS_PER_THREAD = (N_WORDS_MAX + 255) / 256;
+
 __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
 {
-    __shared__ uint32_t s_a[LH_MAX * LW_MAX];
-    __shared__ uint32_t s_b[LH_MAX * LW_MAX];
+    __shared__ uint32_t s_a[N_WORDS_MAX];
+    __shared__ uint32_t s_b[N_WORDS_MAX];
+    __shared__ uint32_t s_inv[N_WORDS_MAX];  // bits outside the image (neutral for every op: OpenCV's morphologyDefaultBorderValue)
     __shared__ unsigned long long s_red[4][6];
 
     const int tid = threadIdx.x;
@@ -84,17 +88,23 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
     const int plane = t;
     const int w = a.w, h = a.h;
     const int LW = TWW + a.hwl + a.hwr, LH = TH + a.ht + a.hb;
+    const uint32_t rcp = (65536u + LW - 1) / LW;  // idx / LW == (idx * rcp) >> 16 for idx < 3277 (LW <= 20)
     const int x_org = (tx * TWW - a.hwl) * 32;  // pixel x of tile word 0
     const int y_org = ty * TH - a.ht;
     const u8 *src = a.thresh + (size_t)plane * w * h;
     const bool vec = ((w & 3) == 0) && (((uintptr_t)src & 3) == 0);
+    auto mask_of = [](int kind) { return kind ? 0xFFFFFFFFu : 0u; };  // dilate(X) = ~erode(~X)
 
-    // ---- pack: one 32-px word per thread-iteration ----
+    // ---- pack: one 32-px word per thread-iteration, stored in the first group's erode domain ----
+    const uint32_t km_first = mask_of(a.groups[0].kind);
     for (int idx = tid; idx < LH * LW; idx += 256) {
-        const int r = idx / LW, k = idx - r * LW;
+        const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LW;
         const int y = y_org + r, x0 = x_org + k * 32;
-        uint32_t bits = 0;
+        uint32_t bits = 0, inv = 0xFFFFFFFFu;
         if (y >= 0 && y < h && x0 < w && x0 + 32 > 0) {
+            inv = 0;
+            if (x0 < 0) inv |= (1u << (-x0)) - 1u;             // x0 in (-32, 0)
+            if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);  // partially beyond the right edge
             const u8 *row = src + (size_t)y * w;
             if (vec && x0 >= 0 && x0 + 32 <= w) {
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x0);
@@ -105,73 +115,60 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
                     if (x0 + i >= 0 && x0 + i < w && row[x0 + i]) bits |= 1u << i;
             }
         }
-        s_a[idx] = bits;
+        s_inv[idx] = inv;
+        s_a[idx] = (bits ^ km_first) | inv;
     }
     __syncthreads();
 
-    uint32_t *cur = s_a, *alt = s_b;
+    // Every group: for each distinct span of its element, a horizontal window AND of the whole tile (cur -> alt), then
+    // the AND over the rows that use that span, accumulated in registers; the result goes back into cur already in the
+    // NEXT group's erode domain.  Rows a group can no longer produce correctly (reach of the groups so far) are skipped.
+    uint32_t *const cur = s_a, *const alt = s_b;
     for (int gi = 0; gi < a.n_groups; gi++) {
-        const Group g = a.groups[gi];
-        const uint32_t km = g.kind ? 0xFFFFFFFFu : 0u;  // dilate(X) = ~erode(~X)
-        if (g.rect) {
-            // horizontal pass (row spans are all equal), written to alt in the erode domain with out-of-image bits = 1
-            for (int idx = tid; idx < LH * LW; idx += 256) {
-                const int r = idx / LW, k = idx - r * LW;
-                const int y = y_org + r;
-                auto ld = [&](int kk) -> uint32_t {
-                    if (kk < 0 || kk >= LW) return 0xFFFFFFFFu;
-                    const int x0 = x_org + kk * 32;
-                    uint32_t inv = 0;
-                    if (y < 0 || y >= h || x0 >= w || x0 + 32 <= 0) inv = 0xFFFFFFFFu;
-                    else {
-                        if (x0 < 0) inv |= (1u << (-x0)) - 1u;          // x0 in (-32, 0)
-                        if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);  // partially beyond the right edge
+        const Group &g = a.groups[gi];
+        const bool last = gi + 1 == a.n_groups;
+        const uint32_t flip = mask_of(g.kind) ^ (last ? 0u : mask_of(a.groups[gi + 1].kind));
+        const int h0 = g.t_in * LW, h1 = (LH - g.b_in) * LW;
+        const int v0 = g.t_out * LW, v1 = (LH - g.b_out) * LW;
+        uint32_t acc[WORDS_PER_THREAD];
+#pragma unroll
+        for (int i = 0; i < WORDS_PER_THREAD; i++) acc[i] = 0xFFFFFFFFu;
+        for (int si = 0; si < g.n_spans; si++) {
+            const Span sp = g.spans[si];
+            const uint32_t *hsrc = cur;
+            if (sp.lx != 0 || sp.hx != 0) {
+                for (int idx = h0 + tid; idx < h1; idx += 256) {
+                    const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LW;
+                    const uint32_t p = k > 0 ? cur[idx - 1] : 0xFFFFFFFFu;
+                    const uint32_t n = k < LW - 1 ? cur[idx + 1] : 0xFFFFFFFFu;
+                    alt[idx] = window_and(p, cur[idx], n, sp.lx, sp.hx);
+                }
+                __syncthreads();
+                hsrc = alt;
+            }
+#pragma unroll
+            for (int i = 0; i < WORDS_PER_THREAD; i++) {
+                const int idx = v0 + tid + 256 * i;
+                if (idx < v1) {
+                    uint32_t x = acc[i];
+                    const uint32_t *col = hsrc + idx + sp.dy_lo * LW;
+                    if (sp.rows == 0) {
+                        for (int d = sp.dy_hi - sp.dy_lo; d >= 0; d--) x &= col[d * LW];
+                    } else {
+                        for (uint32_t m = sp.rows; m; m &= m - 1) x &= col[(__ffs(m) - 1) * LW];
                     }
-                    return (cur[r * LW + kk] ^ km) | inv;
-                };
-                alt[idx] = window_and(ld(k - 1), ld(k), ld(k + 1), g.lx[0], g.hx[0]);
-            }
-            __syncthreads();
-            // vertical pass back into cur
-            const int dy0 = -g.ay, dy1 = g.nrows - 1 - g.ay;
-            for (int idx = tid; idx < LH * LW; idx += 256) {
-                const int r = idx / LW, k = idx - r * LW;
-                uint32_t acc = 0xFFFFFFFFu;
-                for (int dy = dy0; dy <= dy1; dy++) {
-                    const int rr = r + dy;
-                    if (rr >= 0 && rr < LH) acc &= alt[rr * LW + k];  // rows outside the tile: unknown, covered by the halo budget
+                    acc[i] = x;
                 }
-                cur[idx] = acc ^ km;
             }
-            __syncthreads();
-        } else {
-            // one contiguous span per element row (RECT, CROSS, ELLIPSE): AND over the rows of the row's span window
-            for (int idx = tid; idx < LH * LW; idx += 256) {
-                const int r = idx / LW, k = idx - r * LW;
-                uint32_t acc = 0xFFFFFFFFu;
-                for (int j = 0; j < g.nrows; j++) {
-                    if (g.hx[j] < g.lx[j]) continue;  // empty element row
-                    const int rr = r + j - g.ay;
-                    if (rr < 0 || rr >= LH) continue;
-                    const int y = y_org + rr;
-                    auto ld = [&](int kk) -> uint32_t {
-                        if (kk < 0 || kk >= LW) return 0xFFFFFFFFu;
-                        const int x0 = x_org + kk * 32;
-                        uint32_t inv = 0;
-                        if (y < 0 || y >= h || x0 >= w || x0 + 32 <= 0) inv = 0xFFFFFFFFu;
-                        else {
-                            if (x0 < 0) inv |= (1u << (-x0)) - 1u;
-                            if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);
-                        }
-                        return (cur[rr * LW + kk] ^ km) | inv;
-                    };
-                    acc &= window_and(ld(k - 1), ld(k), ld(k + 1), g.lx[j], g.hx[j]);
-                }
-                alt[idx] = acc ^ km;
-            }
-            __syncthreads();
-            uint32_t *tmp = cur; cur = alt; alt = tmp;
+            if (hsrc == alt && si + 1 < g.n_spans) __syncthreads();  // alt is rewritten by the next span
         }
+        __syncthreads();  // every read of cur is done
+#pragma unroll
+        for (int i = 0; i < WORDS_PER_THREAD; i++) {
+            const int idx = v0 + tid + 256 * i;
+            if (idx < v1) cur[idx] = last ? (acc[i] ^ flip) : ((acc[i] ^ flip) | s_inv[idx]);
+        }
+        __syncthreads();
     }
 
     // ---- interior: bytes out + moments ----
@@ -234,13 +231,19 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
 // ---------------------------------------------------------------------------------------------
 // host side: turn the pipeline's element list into groups
 // ---------------------------------------------------------------------------------------------
+namespace {
+struct HostGroup {  // one (possibly merged) erode/dilate while planning
+    int kind, nrows, ay, rect;
+    int lx[128], hx[128];  // per element row (RECT: row 0 only)
+};
+}  // namespace
+
 bool plan_bitmorph(const imgproc_pipeline &pipe, const ipk::Element *elems, Plan *out)
 {
-    Plan p{};
-    p.groups.clear();
+    std::vector<HostGroup> hg;
     for (int i = 0; i < pipe.n_morph; i++) {
         const ipk::Element &e = elems[i];
-        Group g{};
+        HostGroup g{};
         g.kind = pipe.morph[i].kind == IMGPROC_DILATE ? 1 : 0;
         g.nrows = e.kh;
         g.ay = e.ay;
@@ -253,41 +256,66 @@ bool plan_bitmorph(const imgproc_pipeline &pipe, const ipk::Element *elems, Plan
             }
             const int first = __builtin_ctz(bits), last = 31 - __builtin_clz(bits);
             if (bits != ((last == 31 ? 0u : (1u << (last + 1))) - (1u << first))) return false;  // not one contiguous span
-            g.lx[j] = (int8_t)(first - e.ax);
-            g.hx[j] = (int8_t)(last - e.ax);
+            g.lx[j] = first - e.ax;
+            g.hx[j] = last - e.ax;
         }
         // merge with the previous group when both are RECT of the same kind and the merged window stays within +-32
-        if (g.rect && !p.groups.empty()) {
-            Group &q = p.groups.back();
+        if (g.rect && !hg.empty()) {
+            HostGroup &q = hg.back();
             if (q.rect && q.kind == g.kind) {
                 const int lx = q.lx[0] + g.lx[0], hx = q.hx[0] + g.hx[0];
                 const int top = q.ay + g.ay, bot = (q.nrows - 1 - q.ay) + (g.nrows - 1 - g.ay);
                 if (lx >= -32 && hx <= 32 && top + bot + 1 <= 127) {
-                    q.lx[0] = (int8_t)lx; q.hx[0] = (int8_t)hx;
+                    q.lx[0] = lx; q.hx[0] = hx;
                     q.ay = top; q.nrows = top + bot + 1;
                     continue;
                 }
             }
         }
-        p.groups.push_back(g);
+        hg.push_back(g);
     }
+    if (hg.empty() || hg.size() > 32) return false;
+    Plan p{};
     int hl = 0, hr = 0, ht = 0, hb = 0;
-    for (const Group &g : p.groups) {
+    for (const HostGroup &g : hg) {
+        Group d{};
+        d.kind = g.kind;
+        d.t_in = ht; d.b_in = hb;
         int lo = 0, hi = 0;
-        const int nr = g.rect ? 1 : g.nrows;
-        for (int j = 0; j < nr; j++) {
-            if (g.hx[j] < g.lx[j]) continue;
-            lo = g.lx[j] < lo ? g.lx[j] : lo;
-            hi = g.hx[j] > hi ? g.hx[j] : hi;
+        if (g.rect) {
+            d.n_spans = 1;
+            d.spans[0] = Span{(int8_t)g.lx[0], (int8_t)g.hx[0], (int16_t)(-g.ay), (int16_t)(g.nrows - 1 - g.ay), 0u};
+            lo = g.lx[0] < 0 ? g.lx[0] : 0;
+            hi = g.hx[0] > 0 ? g.hx[0] : 0;
+        } else {
+            for (int j = 0; j < g.nrows; j++) {
+                if (g.hx[j] < g.lx[j]) continue;
+                lo = g.lx[j] < lo ? g.lx[j] : lo;
+                hi = g.hx[j] > hi ? g.hx[j] : hi;
+                const int dy = j - g.ay;
+                int si = 0;
+                while (si < d.n_spans && !(d.spans[si].lx == g.lx[j] && d.spans[si].hx == g.hx[j])) si++;
+                if (si == d.n_spans) {
+                    if (d.n_spans == MAX_SPANS) return false;
+                    d.spans[d.n_spans++] = Span{(int8_t)g.lx[j], (int8_t)g.hx[j], (int16_t)dy, (int16_t)dy, 0u};
+                }
+                Span &sp = d.spans[si];  // rows arrive in increasing dy, so dy_lo is already final
+                sp.rows |= 1u << (dy - sp.dy_lo);
+                sp.dy_hi = (int16_t)dy;
+            }
+            if (d.n_spans == 0) {  // an all-empty element: OpenCV then takes the min/max over nothing; keep it off this path
+                return false;
+            }
         }
         hl += -lo; hr += hi;
         ht += g.ay > 0 ? g.ay : 0;
         hb += (g.nrows - 1 - g.ay) > 0 ? (g.nrows - 1 - g.ay) : 0;
+        d.t_out = ht; d.b_out = hb;
+        p.groups.push_back(d);
     }
     p.hwl = (hl + 31) / 32; p.hwr = (hr + 31) / 32;
     p.ht = ht; p.hb = hb;
     if (p.hwl > MAX_HALO_WORDS || p.hwr > MAX_HALO_WORDS || ht + hb > MAX_HALO_ROWS) return false;
-    if (p.groups.size() > 32) return false;
     *out = p;
     return true;
 }
