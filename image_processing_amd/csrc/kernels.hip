@@ -148,45 +148,89 @@ hipError_t launch_gaussian(const u8 *src, size_t sstride, u8 *dst, size_t dstrid
 
 // ---------------------------------------------------------------------------------------------
 // inRange(hsv, lo, hi) for up to 8 ranges at once (objectPolygonPath.cpp:186, pose_estimate.cpp:205):
-// the HSV pixel is read once, one mask plane is written per range.
+// the HSV pixel is read once, one mask plane is written per range.  Per channel a 256-entry byte table in
+// LDS holds, for every value, the set of ranges whose [lo, hi] contains it (bit r = range r); a pixel's
+// membership in ALL ranges is T0[c0] & T1[c1] & T2[c2], and plane r's four bytes are ((m4 >> r) & 0x01010101) * 255.
+// PX pixels per lane: 16 (48-byte loads, 16-byte stores) when rows are 16-byte aligned, else 4.
 // ---------------------------------------------------------------------------------------------
+template <int PX>
 __global__ __launch_bounds__(256) void k_in_range(const u8 *__restrict__ src, size_t sstride, u8 *__restrict__ dst,
                                                   size_t dstride, size_t plane_stride, int w, int h, Bounds b,
                                                   int vec_in, int vec_out)
 {
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= h || x4 >= w) return;
-    const u8 *s = src + (size_t)y * sstride + (size_t)x4 * 3;
-    int c0[4], c1[4], c2[4];
-    const int n = min(4, w - x4);
-    if (vec_in && n == 4) {
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s);
-        uint32_t w0 = s32[0], w1 = s32[1], w2 = s32[2];
-        c0[0] = w0 & 255; c0[1] = w0 >> 24; c0[2] = (w1 >> 16) & 255; c0[3] = (w2 >> 8) & 255;
-        c1[0] = (w0 >> 8) & 255; c1[1] = w1 & 255; c1[2] = w1 >> 24; c1[3] = (w2 >> 16) & 255;
-        c2[0] = (w0 >> 16) & 255; c2[1] = (w1 >> 8) & 255; c2[2] = w2 & 255; c2[3] = w2 >> 24;
-    } else {
-        for (int i = 0; i < 4; i++) {
-            bool in = i < n;
-            c0[i] = in ? s[3 * i] : 0;
-            c1[i] = in ? s[3 * i + 1] : 0;
-            c2[i] = in ? s[3 * i + 2] : 0;
+    __shared__ u8 s_t[3][256];
+    {
+        const int v = threadIdx.y * 64 + threadIdx.x;  // 256 threads: one table column each
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            unsigned m = 0;
+            for (int r = 0; r < b.n; r++) m |= (v >= b.lo[r][c] && v <= b.hi[r][c]) ? (1u << r) : 0u;
+            s_t[c][v] = (u8)m;
         }
     }
-    for (int r = 0; r < b.n; r++) {
-        uint32_t m = 0;
+    __syncthreads();
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * PX;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= h || x0 >= w) return;
+    const u8 *s = src + (size_t)y * sstride + (size_t)x0 * 3;
+    const int n = min(PX, w - x0);
+    constexpr int NW = PX * 3 / 4;
+    uint32_t raw[NW];
+    if (vec_in && n == PX) {
+        if (PX == 16) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(s);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            bool ok = c0[i] >= b.lo[r][0] && c0[i] <= b.hi[r][0] && c1[i] >= b.lo[r][1] && c1[i] <= b.hi[r][1] &&
-                      c2[i] >= b.lo[r][2] && c2[i] <= b.hi[r][2];
-            m |= ok ? (0xFFu << (8 * i)) : 0u;
+            for (int i = 0; i < 3; i++) {
+                const uint4 q = p[i];
+                raw[4 * i] = q.x; raw[4 * i + 1] = q.y; raw[4 * i + 2] = q.z; raw[4 * i + 3] = q.w;
+            }
+        } else {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(s);
+#pragma unroll
+            for (int i = 0; i < NW; i++) raw[i] = p[i];
         }
-        u8 *d = dst + (size_t)r * plane_stride + (size_t)y * dstride + x4;
-        if (vec_out && n == 4)
-            *reinterpret_cast<uint32_t *>(d) = m;
-        else
-            for (int i = 0; i < n; i++) d[i] = (u8)(m >> (8 * i));
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            uint32_t v = 0;
+            for (int j = 0; j < 4; j++)
+                if ((4 * i + j) < 3 * n) v |= (uint32_t)s[4 * i + j] << (8 * j);
+            raw[i] = v;
+        }
+    }
+    uint32_t m4[PX / 4];  // byte k = range set of pixel 4*g + k
+#pragma unroll
+    for (int g = 0; g < PX / 4; g++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int byte0 = 12 * g + 3 * k;
+            uint32_t m = 0xFFu;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int bi = byte0 + c;
+                m &= s_t[c][(raw[bi >> 2] >> (8 * (bi & 3))) & 255u];
+            }
+            acc |= m << (8 * k);
+        }
+        m4[g] = acc;
+    }
+    for (int r = 0; r < b.n; r++) {
+        uint32_t o[PX / 4];
+#pragma unroll
+        for (int g = 0; g < PX / 4; g++) {
+            const uint32_t t = (m4[g] >> r) & 0x01010101u;
+            o[g] = (t << 8) - t;  // * 255 without a multiply; the top byte wraps correctly
+        }
+        u8 *d = dst + (size_t)r * plane_stride + (size_t)y * dstride + x0;
+        if (vec_out && n == PX) {
+            if (PX == 16)
+                *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+            else
+                *reinterpret_cast<uint32_t *>(d) = o[0];
+        } else {
+            for (int i = 0; i < n; i++) d[i] = (u8)(o[i >> 2] >> (8 * (i & 3)));
+        }
     }
 }
 
@@ -194,11 +238,19 @@ hipError_t launch_in_range(const u8 *src, size_t sstride, u8 *dst, size_t dstrid
                            int h, const Bounds &b, hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return hipSuccess;
+    const bool a16 = ((uintptr_t)src % 16 == 0) && (sstride % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (dstride % 16 == 0) &&
+                     (plane_stride % 16 == 0) && w >= 256;
     int vec_in = ((uintptr_t)src % 4 == 0) && (sstride % 4 == 0);
     int vec_out = ((uintptr_t)dst % 4 == 0) && (dstride % 4 == 0) && (plane_stride % 4 == 0);
-    dim3 block(64, 4), grid((w + 255) / 256, (h + 3) / 4);
-    hipLaunchKernelGGL(k_in_range, grid, block, 0, stream, src, sstride, dst, dstride, plane_stride, w, h, b, vec_in,
-                       vec_out);
+    dim3 block(64, 4);
+    if (a16) {
+        dim3 grid((w + 1023) / 1024, (h + 3) / 4);
+        hipLaunchKernelGGL(k_in_range<16>, grid, block, 0, stream, src, sstride, dst, dstride, plane_stride, w, h, b, 1, 1);
+    } else {
+        dim3 grid((w + 255) / 256, (h + 3) / 4);
+        hipLaunchKernelGGL(k_in_range<4>, grid, block, 0, stream, src, sstride, dst, dstride, plane_stride, w, h, b, vec_in,
+                           vec_out);
+    }
     return hipGetLastError();
 }
 
