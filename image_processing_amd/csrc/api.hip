@@ -64,15 +64,18 @@ struct imgproc_ctx {
     ipm::Group *d_groups = nullptr;  // device copy of plan.bm.groups (32 entries)
     std::vector<Slot> slots;
     Plan plan;
-    unsigned long long *d_mom_batch = nullptr, *h_mom_batch = nullptr;
+    struct Batch {  // one of the two in-flight device batches (imgproc_batch_enqueue / imgproc_batch_wait)
+        unsigned long long *d_mom = nullptr, *h_mom = nullptr;
+        hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
+        bool pending = false, timed = false;
+        int n = 0, nr = 0, launches = 0, second = 0;
+    } batch[2];
+    int last_ticket = -1;  // the batch imgproc_last_kernel_ms reports on
     u8 *d_thresh_batch = nullptr;  // inRange planes of a device batch for the front + bit-plane path (grown on demand)
     size_t thresh_batch_bytes = 0;
     u8 *d_s0 = nullptr, *d_s1 = nullptr;  // scratch for single-stage calls (max frame, 3 ch)
     unsigned long long *d_s_mom = nullptr;
     bool profiling = false;
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
-    bool prof_valid = false;
-    int prof_launches = 0;
     unsigned plan_epoch = 1;  // bumped by set_pipeline / set_ranges: invalidates the slots' captured graphs
     int graph_mode = 0;  // IMGPROC_GRAPH: 0 direct launches (default, measured faster), 1 replay a captured hipGraph per frame, 2 graph only for the stage-by-stage chain
     char err[512] = {0};
@@ -369,8 +372,6 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
         HIPCHK(c, hipSetDevice(c->cfg.device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreate(&c->ev_k0));
-        HIPCHK(c, hipEventCreate(&c->ev_k1));
         // HSV reciprocal tables: cvRound == round-half-even == lrint
         int tab[512];
         tab[0] = tab[256] = 0;
@@ -386,8 +387,13 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
         HIPCHK(c, hipMalloc((void **)&c->d_s1, px * 3));
         HIPCHK(c, hipMalloc((void **)&c->d_s_mom, sizeof(unsigned long long) * 6));
         const size_t mb = sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES * (size_t)c->cfg.max_batch;
-        HIPCHK(c, hipMalloc((void **)&c->d_mom_batch, mb));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_mom_batch, mb, hipHostMallocDefault));
+        for (auto &b : c->batch) {
+            HIPCHK(c, hipMalloc((void **)&b.d_mom, mb));
+            HIPCHK(c, hipHostMalloc((void **)&b.h_mom, mb, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreate(&b.ev_k0));
+            HIPCHK(c, hipEventCreate(&b.ev_k1));
+            HIPCHK(c, hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming));
+        }
         c->slots.resize(c->cfg.n_slots);
         for (auto &s : c->slots) {
             int rc = alloc_slot(c, s);
@@ -426,10 +432,13 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     if (c->d_s0) (void)hipFree(c->d_s0);
     if (c->d_s1) (void)hipFree(c->d_s1);
     if (c->d_s_mom) (void)hipFree(c->d_s_mom);
-    if (c->d_mom_batch) (void)hipFree(c->d_mom_batch);
-    if (c->h_mom_batch) (void)hipHostFree(c->h_mom_batch);
-    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
-    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    for (auto &b : c->batch) {
+        if (b.d_mom) (void)hipFree(b.d_mom);
+        if (b.h_mom) (void)hipHostFree(b.h_mom);
+        if (b.ev_k0) (void)hipEventDestroy(b.ev_k0);
+        if (b.ev_k1) (void)hipEventDestroy(b.ev_k1);
+        if (b.ev_done) (void)hipEventDestroy(b.ev_done);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -690,36 +699,47 @@ IMGPROC_API int imgproc_process_batch(imgproc_ctx *c, const uint8_t *frames, siz
     return IMGPROC_OK;
 }
 
-IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frames, size_t frame_stride,
-                                             size_t row_stride, int w, int h, int n, void *d_masks,
-                                             imgproc_result *out)
+// Two batches may be in flight: enqueue returns as soon as the work is on the stream, wait delivers the results.
+IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size_t frame_stride, size_t row_stride,
+                                      int w, int h, int n, void *d_masks, int ticket)
 {
     if (!c || !d_frames || n < 0) return IMGPROC_EINVAL;
+    if (ticket < 0 || ticket > 1) return fail(c, IMGPROC_EINVAL, "ticket %d (0 or 1)", ticket);
     if (n > c->cfg.max_batch) return fail(c, IMGPROC_ESIZE, "batch %d > max_batch %d", n, c->cfg.max_batch);
-    if (n == 0) return IMGPROC_OK;
-    int rc = check_frame(c, w, h, row_stride);
+    imgproc_ctx::Batch &bt = c->batch[ticket];
+    if (bt.pending) return fail(c, IMGPROC_ESTATE, "ticket %d is still in flight: imgproc_batch_wait first", ticket);
+    int rc = n ? check_frame(c, w, h, row_stride) : 0;
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const Plan &p = c->plan;
     const int nr = p.bounds.n;
     const size_t px = (size_t)w * h;
     const size_t mom_bytes = sizeof(unsigned long long) * 6 * nr * (size_t)n;
+    bt.n = n;
+    bt.nr = nr;
+    bt.second = p.pipe.second_order != 0;
+    bt.launches = 0;
+    bt.timed = false;
+    if (n == 0) {
+        bt.pending = true;
+        HIPCHK(c, hipEventRecord(bt.ev_done, c->stream));
+        return IMGPROC_OK;
+    }
     Slot &s = c->slots[0];
     if (s.in_flight) {
         HIPCHK(c, hipEventSynchronize(s.ev_done));
         s.in_flight = false;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_mom_batch, 0, mom_bytes, c->stream));
-    c->prof_valid = false;
-    c->prof_launches = 0;
-    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_k0, c->stream));
+    HIPCHK(c, hipMemsetAsync(bt.d_mom, 0, mom_bytes, c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(bt.ev_k0, c->stream));
     if (p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
-        HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks,
-                                    c->d_mom_batch, c->d_tables, c->stream));
-        c->prof_launches = 1;
+        HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks, bt.d_mom,
+                                    c->d_tables, c->stream));
+        bt.launches = 1;
     } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks)) {
         const size_t need = (size_t)n * nr * px;
         if (need > c->thresh_batch_bytes) {  // grown on demand, kept for the life of the context
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // the other ticket may still be using the old buffer
             if (c->d_thresh_batch) HIPCHK(c, hipFree(c->d_thresh_batch));
             c->d_thresh_batch = nullptr;
             c->thresh_batch_bytes = 0;
@@ -728,31 +748,56 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
         }
         HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, c->d_thresh_batch,
                                     nullptr, c->d_tables, c->stream));
-        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, c->d_thresh_batch, (u8 *)d_masks, c->d_mom_batch, w, h, n * nr,
+        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, c->d_thresh_batch, (u8 *)d_masks, bt.d_mom, w, h, n * nr,
                                        p.pipe.second_order, c->stream));
-        c->prof_launches = 2;
+        bt.launches = 2;
     } else {
         for (int i = 0; i < n; i++) {
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;
             rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)i * frame_stride, row_stride, w, h, mout,
-                             c->d_mom_batch + (size_t)i * nr * 6, &c->prof_launches, c->stream);
+                             bt.d_mom + (size_t)i * nr * 6, &bt.launches, c->stream);
             if (rc) return rc;
         }
     }
     if (c->profiling) {
-        HIPCHK(c, hipEventRecord(c->ev_k1, c->stream));
-        c->prof_valid = true;
+        HIPCHK(c, hipEventRecord(bt.ev_k1, c->stream));
+        bt.timed = true;
     }
+    HIPCHK(c, hipMemcpyAsync(bt.h_mom, bt.d_mom, mom_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(bt.ev_done, c->stream));
+    bt.pending = true;
+    return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_batch_wait(imgproc_ctx *c, int ticket, imgproc_result *out)
+{
+    if (!c) return IMGPROC_EINVAL;
+    if (ticket < 0 || ticket > 1) return fail(c, IMGPROC_EINVAL, "ticket %d (0 or 1)", ticket);
+    imgproc_ctx::Batch &bt = c->batch[ticket];
+    if (!bt.pending) return fail(c, IMGPROC_ESTATE, "ticket %d holds no batch", ticket);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(bt.ev_done));
+    bt.pending = false;
+    c->last_ticket = ticket;
     if (out) {
-        HIPCHK(c, hipMemcpyAsync(c->h_mom_batch, c->d_mom_batch, mom_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int i = 0; i < n; i++) {
+        for (int i = 0; i < bt.n; i++) {
             memset(&out[i], 0, sizeof out[i]);
-            out[i].n_ranges = nr;
-            for (int r = 0; r < nr; r++) finish_moments(c->h_mom_batch + ((size_t)i * nr + r) * 6, out[i].r[r], p.pipe.second_order != 0);
+            out[i].n_ranges = bt.nr;
+            for (int r = 0; r < bt.nr; r++) finish_moments(bt.h_mom + ((size_t)i * bt.nr + r) * 6, out[i].r[r], bt.second != 0);
         }
     }
     return IMGPROC_OK;
+}
+
+IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frames, size_t frame_stride,
+                                             size_t row_stride, int w, int h, int n, void *d_masks,
+                                             imgproc_result *out)
+{
+    if (!c || !d_frames || n < 0) return IMGPROC_EINVAL;
+    if (c->batch[0].pending) return fail(c, IMGPROC_ESTATE, "ticket 0 is in flight (imgproc_batch_enqueue): wait for it first");
+    int rc = imgproc_batch_enqueue(c, d_frames, frame_stride, row_stride, w, h, n, d_masks, 0);
+    if (rc) return rc;
+    return imgproc_batch_wait(c, 0, out);
 }
 
 // ================================================================================================
@@ -968,17 +1013,18 @@ IMGPROC_API int imgproc_set_profiling(imgproc_ctx *c, int on)
 {
     if (!c) return IMGPROC_EINVAL;
     c->profiling = on != 0;
-    c->prof_valid = false;
+    c->last_ticket = -1;
     return IMGPROC_OK;
 }
 IMGPROC_API int imgproc_last_kernel_ms(imgproc_ctx *c, float *ms, int *launches)
 {
     if (!c || !ms) return IMGPROC_EINVAL;
-    if (!c->prof_valid) return fail(c, IMGPROC_ESTATE, "no profiled batch call yet");
+    if (c->last_ticket < 0 || !c->batch[c->last_ticket].timed) return fail(c, IMGPROC_ESTATE, "no profiled batch call yet");
+    const imgproc_ctx::Batch &bt = c->batch[c->last_ticket];
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipEventSynchronize(c->ev_k1));
-    HIPCHK(c, hipEventElapsedTime(ms, c->ev_k0, c->ev_k1));
-    if (launches) *launches = c->prof_launches;
+    HIPCHK(c, hipEventSynchronize(bt.ev_k1));
+    HIPCHK(c, hipEventElapsedTime(ms, bt.ev_k0, bt.ev_k1));
+    if (launches) *launches = bt.launches;
     return IMGPROC_OK;
 }
 IMGPROC_API int imgproc_synchronize(imgproc_ctx *c)

@@ -166,6 +166,21 @@ class ImgProc:
             return res
         return [[_moments_to_dict(res[i].r[j]) for j in range(res[i].n_ranges)] for i in range(n)]
 
+    def batch_enqueue(self, ticket: int, d_frames: int, frame_stride: int, row_stride: int, w: int, h: int, n: int,
+                      d_masks: int | None = None):
+        """Puts a device batch on the stream and returns; two tickets (0, 1) may be in flight."""
+        self._chk(self.lib.imgproc_batch_enqueue(self._ctx, d_frames, frame_stride, row_stride, w, h, n, d_masks, ticket),
+                  "imgproc_batch_enqueue")
+
+    def batch_wait(self, ticket: int, raw=None, n: int | None = None):
+        """Blocks until the ticket's batch is done.  raw: (L.Result * n)() to fill and return; else n is needed to
+        build the list of per-frame, per-range dicts; neither: results are dropped."""
+        res = raw if raw is not None else ((L.Result * n)() if n else None)
+        self._chk(self.lib.imgproc_batch_wait(self._ctx, ticket, res), "imgproc_batch_wait")
+        if res is None or raw is not None:
+            return res
+        return [[_moments_to_dict(res[i].r[j]) for j in range(res[i].n_ranges)] for i in range(n)]
+
     # -- device memory -------------------------------------------------------------------------
     def dev_alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -152,6 +152,13 @@ int imgproc_process_batch(imgproc_ctx *ctx, const uint8_t *frames, size_t frame_
  * d_masks (may be NULL) receives [n][n_ranges][h][w] final masks, out (host) receives n results. */
 int imgproc_process_batch_device(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride, size_t row_stride,
                                  int w, int h, int n, void *d_masks, imgproc_result *out);
+/* The same in two halves, so that two device batches can be in flight (offline bag processing, the benchmark):
+ * enqueue puts batch `ticket` (0 or 1) on the context's stream and returns; wait blocks until it is done and fills
+ * out[n] (out may be NULL).  d_frames / d_masks must stay valid until the wait.  process_batch_device is
+ * enqueue(ticket 0) + wait(0).  Like it, these have no call site in the reference (its nodes see one frame at a time). */
+int imgproc_batch_enqueue(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
+                          int n, void *d_masks, int ticket);
+int imgproc_batch_wait(imgproc_ctx *ctx, int ticket, imgproc_result *out);
 
 /* ---- single stages on host buffers: one entry point per cv:: call on the path ----------------- */
 /* cvtColor(src, dst, CV_BGR2HSV)  objectPolygonPath.cpp:183, pose_estimate.cpp:203; encoding BGR8|RGB8 */
@@ -186,9 +193,9 @@ int imgproc_dev_upload(imgproc_ctx *ctx, void *dptr, const void *src, size_t byt
 int imgproc_dev_download(imgproc_ctx *ctx, void *dst, const void *dptr, size_t bytes);
 
 /* ---- measurement ------------------------------------------------------------------------------
- * With profiling on, process_batch_device brackets its chain kernels with HIP events on the
- * library's own stream; last_kernel_ms returns the device time of the dominant (fused chain)
- * kernel of the last call and how many launches that was. */
+ * With profiling on, every device batch brackets its chain kernels with HIP events on the
+ * library's own stream; last_kernel_ms returns the device time of the chain kernel(s) of the batch
+ * that was waited for last, and how many launches that was. */
 int imgproc_set_profiling(imgproc_ctx *ctx, int on);
 int imgproc_last_kernel_ms(imgproc_ctx *ctx, float *ms, int *launches);
 /* 1 if the current pipeline runs as one fused kernel, 0 if stage-by-stage */

@@ -389,3 +389,34 @@ def test_preblur_and_front_back_variants(gpu, oracle, pre, post, morph, hw):
     for r in range(2):
         assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all()
         check_moments(res[r], exp["moments"][r], second=True)
+
+
+def test_two_batches_in_flight(gpu, oracle):
+    """imgproc_batch_enqueue / imgproc_batch_wait: two tickets in flight deliver the same results as the one-call form."""
+    h, w, n = 64, 256, 4
+    fa, fb = synth_batch(w, h, n, seed=11), synth_batch(w, h, n, seed=12)
+    gpu.set_pipeline(**PRESETS["baseline"])
+    gpu.set_ranges([DEFAULT_RANGE])
+    d_a, d_b = gpu.dev_alloc(fa.nbytes), gpu.dev_alloc(fb.nbytes)
+    d_ma, d_mb = gpu.dev_alloc(n * w * h), gpu.dev_alloc(n * w * h)
+    try:
+        gpu.dev_upload(d_a, fa)
+        gpu.dev_upload(d_b, fb)
+        ref_a = gpu.process_batch_device(d_a, w * h * 3, w * 3, w, h, n, d_ma)
+        ref_b = gpu.process_batch_device(d_b, w * h * 3, w * 3, w, h, n, d_mb)
+        gpu.batch_enqueue(0, d_a, w * h * 3, w * 3, w, h, n, d_ma)
+        gpu.batch_enqueue(1, d_b, w * h * 3, w * 3, w, h, n, d_mb)
+        with pytest.raises(ip.ImgProcError):
+            gpu.batch_enqueue(1, d_b, w * h * 3, w * 3, w, h, n, d_mb)  # ticket busy
+        with pytest.raises(ip.ImgProcError):
+            gpu.process_batch_device(d_a, w * h * 3, w * 3, w, h, n, d_ma)  # uses ticket 0
+        assert gpu.batch_wait(1, n=n) == ref_b
+        assert gpu.batch_wait(0, n=n) == ref_a
+        with pytest.raises(ip.ImgProcError):
+            gpu.batch_wait(0)
+        exp = oracle.chain(fb[2], post_blur_k=5, morph=morph_tuples(ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE], stages=False)
+        assert (gpu.dev_download(d_mb, (n, h, w))[2] == exp["mask"][0]).all()
+        check_moments(ref_b[2][0], exp["moments"][0])
+    finally:
+        for p in (d_a, d_b, d_ma, d_mb):
+            gpu.dev_free(p)
