@@ -538,17 +538,28 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     }
     const Plan &p = c->plan;
     const size_t rowb = (size_t)w * (p.pipe.encoding == IMGPROC_ENC_BAYER_RGGB8 ? 1 : 3);
-    if (stride == rowb)
-        memcpy(s.h_in, data, rowb * h);
-    else
-        for (int y = 0; y < h; y++) memcpy(s.h_in + (size_t)y * rowb, data + (size_t)y * stride, rowb);
+    // Staging: the caller's frame goes into the slot's pinned buffer (so msg->data may be released on return) and from
+    // there to HBM.  Large frames go in row chunks, each chunk's DMA starting while the CPU copies the next one; with a
+    // captured graph (IMGPROC_GRAPH) the whole-frame H2D is part of the graph instead.
+    const bool graph_path = c->graph_mode != 0;
+    const int n_chunks = (!graph_path && rowb * h >= (1u << 20)) ? 4 : 1;
+    for (int ci = 0; ci < n_chunks; ci++) {
+        const int y0 = (int)((long long)h * ci / n_chunks), y1 = (int)((long long)h * (ci + 1) / n_chunks);
+        if (stride == rowb)
+            memcpy(s.h_in + (size_t)y0 * rowb, data + (size_t)y0 * stride, rowb * (size_t)(y1 - y0));
+        else
+            for (int y = y0; y < y1; y++) memcpy(s.h_in + (size_t)y * rowb, data + (size_t)y * stride, rowb);
+        if (!graph_path)
+            HIPCHK(c, hipMemcpyAsync(s.d_raw + (size_t)y0 * rowb, s.h_in + (size_t)y0 * rowb, rowb * (size_t)(y1 - y0),
+                                     hipMemcpyHostToDevice, s.stream));
+    }
     // The per-frame work {H2D, memset, chain kernels, D2H of the moments} has fixed pointers and sizes for a given
     // (slot, w, h, plan): it is captured once into a hipGraph and replayed with one hipGraphLaunch per frame.
     // 0: chain kernel, 1: front kernel + bit-plane back end, 2: stage by stage
     const int path = (p.fused_ok && ipf::can_launch_fused(p.fused, s.d_raw, 0, rowb, w, h, s.d_mask)) ? 0
                      : (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, s.d_raw, 0, rowb, w, h, s.d_thresh)) ? 1 : 2;
     auto enqueue = [&](hipStream_t st) -> int {
-        HIPCHK(c, hipMemcpyAsync(s.d_raw, s.h_in, rowb * h, hipMemcpyHostToDevice, st));
+        if (graph_path) HIPCHK(c, hipMemcpyAsync(s.d_raw, s.h_in, rowb * h, hipMemcpyHostToDevice, st));
         const int nr = p.bounds.n;
         HIPCHK(c, hipMemsetAsync(s.d_mom, 0, sizeof(unsigned long long) * 6 * nr, st));
         if (path == 0) {

@@ -22,6 +22,8 @@
 //    as one dword per lane and row (256 B per wave row, coalesced).
 #include "fused.h"
 
+#include <algorithm>
+
 namespace ipf {
 
 using ipk::u8;
@@ -692,15 +694,21 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     a.w = w;
     a.h = h;
     a.n = n;
+    const int sv = strip_valid(plan.bayer != 0);
+    a.n_strips = (w + sv - 1) / sv;
     int target = g_seg_rows_override > 0 ? g_seg_rows_override : 200;
+    if (g_seg_rows_override <= 0) {
+        // Small jobs (the live node: ONE frame per callback) are latency-bound: a 200-row segment is one wave's serial
+        // work.  Shorter segments (more look-ahead rows re-done, a few % more work) until the chip has ~6 waves per CU.
+        const long long items200 = (long long)a.n_strips * ((h + 199) / 200) * n;
+        if (items200 < 1536) target = std::max(32, (int)((long long)h * a.n_strips * n / 1536));
+    }
     a.n_segs = (h + target - 1) / target;
     a.seg_rows = (h + a.n_segs - 1) / a.n_segs;
     if (a.seg_rows > 512) {  // u32 moment partials are sized for <= 512 rows per segment
         a.seg_rows = 512;
         a.n_segs = (h + 511) / 512;
     }
-    const int sv = strip_valid(plan.bayer != 0);
-    a.n_strips = (w + sv - 1) / sv;
     a.total_items = a.n_strips * a.n_segs * n;
     a.op0 = plan.kind[0];
     a.op1 = plan.kind[1];
