@@ -40,6 +40,8 @@ struct Args {
     const int *tables;
     int w, h, n;
     int seg_rows, n_segs, n_strips, total_items;
+    int last_base;  // first valid column of the last strip: (n_strips-1)*SV, or w - SV (right-aligned) when w % 4 != 0
+    int split_x;    // the last strip owns columns >= split_x, the others own [strip*SV, min((strip+1)*SV, split_x))
     int op0, op1;  // 0 erode3, 1 dilate3, 2 identity (one-row delay only)
     uint32_t hs_lo[MAX_NR], hs_hi[MAX_NR], v_lo[MAX_NR], v_hi[MAX_NR];
 };
@@ -335,6 +337,14 @@ __device__ __forceinline__ uint32_t rows_outside(int y0, int lo, int hi)  // nib
     return m;
 }
 
+// the owned bytes of a lane that straddles an ownership boundary (px = address of the lane's pixel 0)
+__device__ __forceinline__ void store_part(u8 *px, uint32_t bytes, uint32_t own)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (own & (1u << k)) px[k] = (u8)(bytes >> (8 * k));
+}
+
 // MODE 0: whole chain (up to two 3x3 ops, moments, final mask).  MODE 1: front end only: the inRange output is
 // written as 0/255 bytes to a.masks (the bit-plane back end, morphbits.hip, runs the morph list and the moments).
 // BAYER: the frames are BayerRG8 mosaics (1 B/px); every fed row loads the three mosaic rows it is interpolated from.
@@ -362,12 +372,26 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const int ye = min(ys + a.seg_rows, h);
     constexpr int HL = BAYER ? 2 : 1;  // halo lanes per side
     constexpr int SV = strip_valid(BAYER);
-    const int x0 = strip * SV - 4 * HL + lane * 4;
+    // Strips are left-aligned (lane columns = 0 mod 4, so the image's left border is a lane boundary) except the last
+    // one when w % 4 != 0: that one is right-aligned (a lane boundary at w).  Every strip is then wrong only within
+    // the blur/morph reach of the border it is NOT aligned to, and never owns columns there (launch_fused).
+    const bool last_strip = strip == a.n_strips - 1;
+    const int base = last_strip ? a.last_base : strip * SV;
+    const int x0 = base - 4 * HL + lane * 4;
+    const int own_lo = last_strip ? a.split_x : strip * SV;
+    const int own_hi = last_strip ? w : min((strip + 1) * SV, a.split_x);
     const int xl = min(max(x0, 0), w - 4);
     const bool in_image = x0 >= 0 && x0 < w;
-    const bool lane_out = in_image && lane >= HL && lane <= 63 - HL;
+    uint32_t own = 0;  // bit k: this lane's pixel k is an output of this strip
+    if (lane >= HL && lane <= 63 - HL) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) own |= (x0 + k >= own_lo && x0 + k < own_hi) ? (1u << k) : 0u;
+    }
+    const bool lane_out = own == 0xFu;              // the common case: one dword store per row
+    const bool lane_part = own != 0u && own != 0xFu;  // ownership boundary inside the lane (w % 4 != 0 only)
+    const uint32_t own_rep = own * 0x11111111u;
     const bool strip_left = strip == 0;
-    const bool strip_right = strip * SV + 256 - 4 * HL >= w;
+    const bool strip_right = base + 256 - 4 * HL >= w;
     const bool lb_halo = x0 == -4, rb_halo = x0 == w;  // halo lanes just outside the left / right image border
     const uint32_t colinv = in_image ? 0u : 0xFFFFFFFFu;
 
@@ -514,11 +538,14 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
                     const int y = yt + p;
-                    if (y >= ys && y < ye && lane_out) {
+                    if (y >= ys && y < ye && (lane_out || lane_part)) {
                         const int sh = 4 * (7 - p) - 2;
                         const uint32_t idx = (sh >= 0 ? (t >> sh) : (t << 2)) & 0x3Cu;
-                        *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) =
-                            *reinterpret_cast<const uint32_t *>(tab + 2048 + idx);
+                        const uint32_t bytes = *reinterpret_cast<const uint32_t *>(tab + 2048 + idx);
+                        if (lane_out)
+                            *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = bytes;
+                        else
+                            store_part(rowp + ((long long)p * w + x0), bytes, own);
                     }
                 }
             }
@@ -527,7 +554,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
         // ---- one 4x8 tile per range is complete: morphology, store, moments ----
         const uint32_t inv1 = colinv | rows_outside(yt, 0, h);
         const uint32_t inv2 = colinv | rows_outside(yt - 1, 0, h);
-        const uint32_t keep = lane_out ? ~rows_outside(yt - 2, ys, ye) : 0u;
+        const uint32_t keep = own_rep & ~rows_outside(yt - 2, ys, ye);
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             uint32_t t = morph3(acc[r], prev1[r], a.op0, inv1);
@@ -546,6 +573,9 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 #pragma unroll
                         for (int p = 0; p < 8; p++)
                             *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = expand(t, p);
+                    } else if (lane_part) {
+#pragma unroll
+                        for (int p = 0; p < 8; p++) store_part(rowp + ((long long)p * w + x0), expand(t, p), own);
                     }
                 } else {
 #pragma unroll
@@ -553,6 +583,8 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
                         const int y = yt - 2 + p;
                         if (y >= ys && y < ye && lane_out)
                             *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = expand(t, p);
+                        else if (y >= ys && y < ye && lane_part)
+                            store_part(rowp + ((long long)p * w + x0), expand(t, p), own);
                     }
                 }
             }
@@ -666,10 +698,14 @@ bool plan_front(const imgproc_pipeline &pipe, const ipk::Bounds &bounds, FusedPl
 bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
                       const void *d_masks)
 {
-    if (w < 4 || (w & 3) || h < 1 || w > 16384 || h > 16384) return false;
+    if (w < 4 || h < 1 || w > 16384 || h > 16384) return false;
+    // w % 4 != 0 (tracker ROI crops, pose_estimate.cpp:197-202) runs with a right-aligned last strip: needs room for
+    // two strips' unaligned-border zones, and an even width for the Bayer phase.  Dword accesses may then be unaligned,
+    // which gfx950 global memory handles (scripts/ubench/unaligned.hip).
+    if ((w & 3) && (w < 32 || (plan.bayer && (w & 1)))) return false;
     if (plan.bayer && h < 3) return false;  // no interior row: OpenCV writes zeros, the stage kernel does that
     if ((unsigned long long)row_stride * (unsigned long long)h >= (1ull << 32)) return false;  // 32-bit in-frame offsets
-    if (((uintptr_t)d_frames & 3) || (frame_stride & 3) || (row_stride & 3) || ((uintptr_t)d_masks & 3)) return false;
+    (void)d_frames; (void)frame_stride; (void)d_masks;
     return true;
 }
 
@@ -696,6 +732,12 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     a.n = n;
     const int sv = strip_valid(plan.bayer != 0);
     a.n_strips = (w + sv - 1) / sv;
+    a.last_base = a.split_x = (a.n_strips - 1) * sv;
+    if (w & 3) {
+        a.n_strips = std::max(2, a.n_strips);
+        a.last_base = w - sv;
+        a.split_x = std::min((a.n_strips - 1) * sv, (w - 16) & ~3);
+    }
     int target = g_seg_rows_override > 0 ? g_seg_rows_override : 200;
     if (g_seg_rows_override <= 0) {
         // Small jobs (the live node: ONE frame per callback) are latency-bound: a 200-row segment is one wave's serial

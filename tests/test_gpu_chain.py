@@ -420,3 +420,38 @@ def test_two_batches_in_flight(gpu, oracle):
     finally:
         for p in (d_a, d_b, d_ma, d_mb):
             gpu.dev_free(p)
+
+
+@pytest.mark.parametrize("w", [32, 33, 37, 101, 249, 250, 251, 255, 257, 499, 501, 997])
+@pytest.mark.parametrize("preset", ["pose_estimate", "baseline", "polygon_path"])
+def test_odd_widths_stay_on_the_fast_path(gpu, oracle, w, preset):
+    """Widths that are not a multiple of 4 (tracker ROI crops, pose_estimate.cpp:197-202): the last strip is
+    right-aligned, dword accesses are unaligned, and the chain still runs as one launch (front + bit planes: two)."""
+    h, n = 45, 2
+    kw = PRESETS[preset]
+    for enc in ("bgr", "bayer"):
+        if enc == "bayer" and (w & 1):
+            continue
+        rng = np.random.default_rng(w * 3 + len(preset))
+        frames = rng.integers(0, 256, (n, h, w) if enc == "bayer" else (n, h, w, 3), dtype=np.uint8)
+        frames[:, 5:30, 3:w - 2] //= 2  # some structure for the morphology
+        ranges = [((0, 30, 40), (100, 256, 256))]
+        gpu.set_pipeline(encoding=L.ENC_BAYER_RGGB8 if enc == "bayer" else L.ENC_BGR8, second_order=True, **kw)
+        gpu.set_ranges(ranges)
+        gpu.set_profiling(True)
+        d_in, d_out = gpu.dev_alloc(frames.nbytes), gpu.dev_alloc(n * w * h)
+        try:
+            gpu.dev_upload(d_in, frames)
+            cn = 1 if enc == "bayer" else 3
+            res = gpu.process_batch_device(d_in, w * h * cn, w * cn, w, h, n, d_out)
+            assert gpu.last_kernel_ms()[1] == (1 if preset != "polygon_path" else 2), (w, preset, enc)
+            masks = gpu.dev_download(d_out, (n, h, w))
+        finally:
+            gpu.dev_free(d_in)
+            gpu.dev_free(d_out)
+        for i in range(n):
+            exp = oracle.chain(frames[i], encoding=2 if enc == "bayer" else 0, pre_blur_k=kw["pre_blur_k"],
+                               post_blur_k=kw["post_blur_k"], morph=morph_tuples(kw["morph"]), ranges=ranges, stages=False)
+            assert (masks[i] == exp["mask"][0]).all(), (w, preset, enc, i)
+            check_moments(res[i][0], exp["moments"][0], second=True)
+    gpu.set_profiling(False)
