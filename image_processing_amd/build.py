@@ -8,8 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libimgproc_hip.so")
-SOURCES = ["api.hip", "kernels.hip", "fused.hip", "morphbits.hip", "gauss.hip"]
-HEADERS = ["kernels.h", "fused.h", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
+SOURCES = ["api.hip", "kernels.hip", "fused.hip", "fused_inst_plain_small.hip", "fused_inst_plain_large.hip",
+           "fused_inst_bayer_small.hip", "fused_inst_bayer_large.hip", "morphbits.hip", "gauss.hip"]
+HEADERS = ["kernels.h", "fused.h", "fused_kernel.hpp", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
 
 

@@ -1,0 +1,704 @@
+// Fused chain kernel for gfx950 (template + device helpers; instantiated in fused_inst_*.hip, planned and
+// launched from fused.hip)
+// Fused chain kernel for gfx950: BGR/RGB -> HSV -> [5x5 Gaussian] -> inRange -> up to two 3x3 rect
+// erode/dilate -> mask bytes + raster moments, one launch for a whole batch of frames.
+//
+// Replaces, for the pipelines plan_fused() accepts, the OpenCV call sequence of
+// objectPolygonPath.cpp:183-188 / pose_estimate.cpp:203-206 (cvtColor, GaussianBlur 5x5, inRange,
+// erode, dilate) and the m00/m10/m01 sums of moments() (objectPolygonPath.cpp:449-450).
+// Arithmetic: SURVEY.md Appendix A, bit-exact with the stage kernels and the oracle.
+//
+// Design (MI355X: HBM-bound u8 work, no MFMA):
+//  * One WAVE owns a strip of 256 columns (4 px per lane = one 12-byte load per lane and row; lanes 0
+//    and 63 are halo) and marches down a segment of rows.  Waves never talk to each other: no
+//    barriers after the table load, no LDS tiles, no vertical halo re-computation inside a segment.
+//  * HSV rows live in a register ring; the vertical 1-4-6-4-1 pass runs on it, the horizontal pass
+//    gets its +-2 px neighbours from the adjacent lanes with DPP wave shifts.
+//  * Pixels are kept as packed 16-bit fields (H|S<<16 per pixel, V pairs), so every Gaussian add /
+//    shift-add processes two values per VALU op; sums stay < 2^16 per field (max 255*256+128).
+//    The single rounding (x+128)>>8 is folded in as +8 in the vertical pass and never materialised:
+//    inRange compares the 8.8 field against (lo<<8, hi<<8|255).
+//  * inRange results are shifted into a per-lane 4-col x 8-row bit tile; 3x3 erode/dilate are a dozen
+//    bit operations on that tile (horizontal neighbours again by DPP), 32 pixels per op.
+//  * Moments are popcounts of the final tile; mask bytes are expanded from the tile rows and stored
+//    as one dword per lane and row (256 B per wave row, coalesced).
+#pragma once
+#include "fused.h"
+
+#include <algorithm>
+
+namespace ipf {
+
+using ipk::u8;
+
+constexpr int strip_valid(bool bayer) { return bayer ? 240 : 248; }  // valid output columns per wave: lanes 1..62, or
+                                                                     // 2..61 when the Bayer front end adds a column of reach
+constexpr int MAX_NR = 8;  // kernel variants hold 1, 2, 4 or 8 ranges; a.nr of them are live
+
+struct Args {
+    const u8 *frames;
+    size_t frame_stride, row_stride;
+    u8 *masks;
+    unsigned long long *mom;
+    const int *tables;
+    int w, h, n;
+    int nr;  // live ranges (== NR for the 1- and 2-range variants)
+    int seg_rows, n_segs, n_strips, total_items;
+    int last_base;  // first valid column of the last strip: (n_strips-1)*SV, or w - SV (right-aligned) when w % 4 != 0
+    int split_x;    // the last strip owns columns >= split_x, the others own [strip*SV, min((strip+1)*SV, split_x))
+    int op0, op1;  // 0 erode3, 1 dilate3, 2 identity (one-row delay only)
+    uint32_t hs_lo[MAX_NR], hs_hi[MAX_NR], v_lo[MAX_NR], v_hi[MAX_NR];
+};
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t from_left(uint32_t v)  // lane l <- lane l-1
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xF, 0xF, true);  // bound_ctrl: lane 0 reads 0
+}
+__device__ __forceinline__ uint32_t from_right(uint32_t v)  // lane l <- lane l+1
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xF, 0xF, true);
+}
+// x[lane-1] + y and x[lane+1] + y in one instruction (lane 0 / lane 63 read 0)
+__device__ __forceinline__ uint32_t add_from_left(uint32_t x, uint32_t y)
+{
+    uint32_t r;
+    asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_from_right(uint32_t x, uint32_t y)
+{
+    uint32_t r;
+    asm("v_add_u32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, int sh)  // ({hi:lo} >> sh) low 32
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+__device__ __forceinline__ uint32_t pk_clamp(uint32_t x, uint32_t lo, uint32_t hi)
+{
+    us2 a = __builtin_bit_cast(us2, x), l = __builtin_bit_cast(us2, lo), h = __builtin_bit_cast(us2, hi);
+    us2 c = __builtin_elementwise_min(__builtin_elementwise_max(a, l), h);
+    return __builtin_bit_cast(uint32_t, c);
+}
+// hipcc does not reliably select the 24-bit multiply-adds (it falls back to quarter-rate v_mul_lo_u32 /
+// v_mad_u64_u32), so they are spelled out.
+__device__ __forceinline__ int mad_i24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int max3u(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int min3u(int a, int b, int c)
+{
+    int r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// t = 2*t + bit, the bit coming straight from the compare's lane mask (carry-in)
+__device__ __forceinline__ uint32_t shift_in(uint32_t t, unsigned long long m)
+{
+    uint32_t r;
+    asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(t), "s"(m) : "vcc");
+    return r;
+}
+// BORDER_REFLECT_101 for the rows this kernel can ask for (|overshoot| < h for every row a valid output
+// depends on; rows beyond that are prefetch overshoot and only need to stay inside the frame)
+__device__ __forceinline__ int reflect_row(int r, int h)
+{
+    r = abs(r);
+    r = r >= h ? 2 * (h - 1) - r : r;
+    return min(abs(r), h - 1);
+}
+
+// One pixel of cvtColor(BGR2HSV).  Inputs are the channel bytes times 4 (they double as
+// byte offsets into the LDS reciprocal tables); (d*4*sdiv + 2^13) >> 14 == (d*sdiv + 2^11) >> 12.
+template <bool RGB>
+__device__ __forceinline__ void hsv_px(uint32_t c0, uint32_t c1, uint32_t c2, const char *tab, uint32_t &hs,
+                                       uint32_t &v)
+{
+    const int b4 = RGB ? c2 : c0, g4 = c1, r4 = RGB ? c0 : c2;
+    const int v4 = max3u(b4, g4, r4), m4 = min3u(b4, g4, r4), d4 = v4 - m4;
+    const int sdiv4 = *reinterpret_cast<const int *>(tab + v4);        // 4 * sdiv[v]
+    const int hdiv = *reinterpret_cast<const int *>(tab + 1024 + d4);  // hdiv180[diff]
+    // S << 16 == ((d*sdiv + 2^11) >> 12) << 16 == (4d * 4sdiv + 2^15) & 0xFFFF0000   (4d*4sdiv <= 2^24)
+    const uint32_t s16 = mad_u24((uint32_t)d4, (uint32_t)sdiv4, 32768u) & 0xFFFF0000u;
+    int hr = g4 - b4, hg = (b4 - r4) + 2 * d4, hb = (r4 - g4) + 4 * d4;
+    asm("" : "+v"(hr), "+v"(hg), "+v"(hb));  // keep the three candidates live: selects, not branches
+    const int hh = (v4 == r4) ? hr : (v4 == g4) ? hg : hb;
+    const int x = mad_i24(hh, hdiv, 8192);
+    const int h = mad_i24(x >> 31, -180, x >> 14);  // (x >> 14) + (x < 0 ? 180 : 0)
+    hs = (uint32_t)h | s16;
+    v = (uint32_t)v4;  // still times 4; hsv_row unscales a packed pair with one shift
+}
+
+struct Row {  // one row of this lane's 4 pixels as packed 16-bit fields
+    uint32_t hs[4];  // px k: H | S<<16
+    uint32_t v[2];   // (V0,V1), (V2,V3)
+};
+
+template <bool RGB>
+__device__ __forceinline__ void hsv_row(const uint32_t (&w)[3], const char *tab, Row &o)
+{
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    uint32_t vv[4];
+    hsv_px<RGB>((w0 & 0xFF) << 2, ((w0 >> 8) & 0xFF) << 2, ((w0 >> 16) & 0xFF) << 2, tab, o.hs[0], vv[0]);
+    hsv_px<RGB>((w0 >> 24) << 2, (w1 & 0xFF) << 2, ((w1 >> 8) & 0xFF) << 2, tab, o.hs[1], vv[1]);
+    hsv_px<RGB>(((w1 >> 16) & 0xFF) << 2, (w1 >> 24) << 2, (w2 & 0xFF) << 2, tab, o.hs[2], vv[2]);
+    hsv_px<RGB>(((w2 >> 8) & 0xFF) << 2, ((w2 >> 16) & 0xFF) << 2, (w2 >> 24) << 2, tab, o.hs[3], vv[3]);
+    o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;  // 4*V0 is a multiple of 4: no bits cross the field boundary
+    o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
+}
+
+struct RowBGR {  // one raw row of this lane's 4 pixels as packed 16-bit fields (channel order as in memory)
+    uint32_t c01[4];  // px k: c0 | c1<<16
+    uint32_t c2[2];   // (c2 of px0, px1), (px2, px3)
+};
+
+__device__ __forceinline__ void unpack_row(const uint32_t (&w)[3], RowBGR &o)
+{
+    // v_perm_b32 byte selectors: 0-3 = bytes of the second operand, 4-7 = bytes of the first, 0x0C = 0x00
+    o.c01[0] = __builtin_amdgcn_perm(w[0], w[0], 0x0C010C00u);
+    o.c01[1] = __builtin_amdgcn_perm(w[1], w[0], 0x0C040C03u);
+    o.c01[2] = __builtin_amdgcn_perm(w[1], w[1], 0x0C030C02u);
+    o.c01[3] = __builtin_amdgcn_perm(w[2], w[2], 0x0C020C01u);
+    o.c2[0] = __builtin_amdgcn_perm(w[1], w[0], 0x0C050C02u);
+    o.c2[1] = __builtin_amdgcn_perm(w[2], w[2], 0x0C030C00u);
+}
+
+// GaussianBlur 3x3 (objectPolygonPath.cpp:182) on the raw channels, then HSV.  Fields hold 16*value + 8 after the two
+// 1-2-1 passes (the +8 is the folded rounding: +2 per field in the vertical pass times the horizontal weight 4), so the
+// channel value times 4 that hsv_px wants is (field >> 2) & 0x3FC.
+template <bool RGB>
+__device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &r1, const RowBGR &r2, bool border_strip,
+                                                bool lb_halo, bool rb_halo, const char *tab, Row &o)
+{
+    uint32_t v[4], u[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = r0.c01[k] + r2.c01[k] + 0x00020002u + (r1.c01[k] << 1);
+#pragma unroll
+    for (int k = 0; k < 2; k++) u[k] = r0.c2[k] + r2.c2[k] + 0x00020002u + (r1.c2[k] << 1);
+    if (border_strip) {  // BORDER_REFLECT_101 left/right: col -1 = col 1, col w = col w-2 (see the post-blur patch)
+        const uint32_t a1 = from_right(v[1]), au = from_right(u[0]);  // lane+1's px1 / (R0,R1)
+        const uint32_t b2 = from_left(v[2]), bu = from_left(u[1]);    // lane-1's px2 / (R2,R3)
+        if (lb_halo) { v[3] = a1; u[1] = au; }
+        if (rb_halo) { v[0] = b2; u[0] = bu; }
+    }
+    uint32_t h01[4], h2[2];
+    h01[0] = add_from_left(v[3], v[1]) + (v[0] << 1);
+    h01[1] = v[0] + v[2] + (v[1] << 1);
+    h01[2] = v[1] + v[3] + (v[2] << 1);
+    h01[3] = add_from_right(v[0], v[2]) + (v[3] << 1);
+    const uint32_t ul = from_left(u[1]), ur = from_right(u[0]);
+    const uint32_t m1 = alignbit(u[0], ul, 16);    // (c2[-1], c2[0])
+    const uint32_t m2 = alignbit(u[1], u[0], 16);  // (c2[1], c2[2])
+    const uint32_t m3 = alignbit(ur, u[1], 16);    // (c2[3], c2[4])
+    h2[0] = m1 + m2 + (u[0] << 1);
+    h2[1] = m2 + m3 + (u[1] << 1);
+    uint32_t vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t f2 = h2[k >> 1];
+        const uint32_t c2 = (k & 1) ? ((f2 >> 18) & 0x3FCu) : ((f2 >> 2) & 0x3FCu);
+        hsv_px<RGB>((h01[k] >> 2) & 0x3FCu, (h01[k] >> 18) & 0x3FCu, c2, tab, o.hs[k], vv[k]);
+    }
+    o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;
+    o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
+}
+
+// BayerRG8 front end (cv_bridge's bayer_rggb8 -> bgr8 == COLOR_BayerBG2BGR at pose_estimate.cpp:180):
+// bilinear demosaic of this lane's 4 pixels from the three mosaic rows y-1, y, y+1 (one dword each), SWAR on byte
+// pairs.  Index [0] holds pixels (0,2) = even columns, [1] holds pixels (1,3) = odd columns, as 16-bit fields.
+struct Pairs {
+    uint32_t b[2], g[2], r[2];
+};
+
+__device__ __forceinline__ void demosaic_row(const uint32_t (&w)[3], bool odd_row, bool border_strip, bool first_col,
+                                             bool last_col, Pairs &o)
+{
+    const uint32_t M8 = 0x00FF00FFu;
+    const uint32_t me = w[1] & M8, mo = (w[1] >> 8) & M8;                                          // centre row
+    const uint32_t vse = (w[0] & M8) + (w[2] & M8), vso = ((w[0] >> 8) & M8) + ((w[2] >> 8) & M8);  // up + down
+    const uint32_t hme = mo + alignbit(mo, from_left(mo), 16);   // left + right of the even columns: cols (-1,1) + (1,3)
+    const uint32_t hmo = me + alignbit(from_right(me), me, 16);  // left + right of the odd columns:  cols (0,2) + (2,4)
+    if (!odd_row) {  // R G R G: even columns are R sites, odd columns G with R left/right and B above/below
+        const uint32_t hve = vso + alignbit(vso, from_left(vso), 16);  // the four diagonals of the even columns
+        o.r[0] = me;
+        o.g[0] = ((hme + vse + 0x00020002u) >> 2) & M8;
+        o.b[0] = ((hve + 0x00020002u) >> 2) & M8;
+        o.g[1] = mo;
+        o.r[1] = ((hmo + 0x00010001u) >> 1) & M8;
+        o.b[1] = ((vso + 0x00010001u) >> 1) & M8;
+    } else {  // G B G B: odd columns are B sites, even columns G with B left/right and R above/below
+        const uint32_t hvo = vse + alignbit(from_right(vse), vse, 16);
+        o.g[0] = me;
+        o.b[0] = ((hme + 0x00010001u) >> 1) & M8;
+        o.r[0] = ((vse + 0x00010001u) >> 1) & M8;
+        o.b[1] = mo;
+        o.g[1] = ((hmo + vso + 0x00020002u) >> 2) & M8;
+        o.r[1] = ((hvo + 0x00020002u) >> 2) & M8;
+    }
+    if (border_strip) {  // OpenCV leaves no interpolated border: column 0 copies column 1, column w-1 copies w-2
+        if (first_col) {
+            o.b[0] = (o.b[0] & 0xFFFF0000u) | (o.b[1] & 0xFFFFu);
+            o.g[0] = (o.g[0] & 0xFFFF0000u) | (o.g[1] & 0xFFFFu);
+            o.r[0] = (o.r[0] & 0xFFFF0000u) | (o.r[1] & 0xFFFFu);
+        }
+        if (last_col) {
+            o.b[1] = (o.b[1] & 0xFFFFu) | (o.b[0] & 0xFFFF0000u);
+            o.g[1] = (o.g[1] & 0xFFFFu) | (o.g[0] & 0xFFFF0000u);
+            o.r[1] = (o.r[1] & 0xFFFFu) | (o.r[0] & 0xFFFF0000u);
+        }
+    }
+}
+
+__device__ __forceinline__ void hsv_row_pairs(const Pairs &p, const char *tab, Row &o)
+{
+    uint32_t vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = k & 1, sh = (k >> 1) * 16;
+        hsv_px<false>(((p.b[q] >> sh) & 0xFFFFu) << 2, ((p.g[q] >> sh) & 0xFFFFu) << 2, ((p.r[q] >> sh) & 0xFFFFu) << 2, tab,
+                      o.hs[k], vv[k]);
+    }
+    o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;
+    o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
+}
+
+__device__ __forceinline__ void pairs_to_row(const Pairs &p, RowBGR &o)
+{
+    o.c01[0] = __builtin_amdgcn_perm(p.g[0], p.b[0], 0x05040100u);
+    o.c01[1] = __builtin_amdgcn_perm(p.g[1], p.b[1], 0x05040100u);
+    o.c01[2] = __builtin_amdgcn_perm(p.g[0], p.b[0], 0x07060302u);
+    o.c01[3] = __builtin_amdgcn_perm(p.g[1], p.b[1], 0x07060302u);
+    o.c2[0] = __builtin_amdgcn_perm(p.r[1], p.r[0], 0x05040100u);
+    o.c2[1] = __builtin_amdgcn_perm(p.r[1], p.r[0], 0x07060302u);
+}
+
+// vertical 1-4-6-4-1 on packed fields, +8 per field (the folded rounding)
+__device__ __forceinline__ uint32_t vert5(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4)
+{
+    uint32_t t = a0 + a4 + 0x00080008u;
+    t += (a1 + a3) << 2;
+    return mad_u24(a2, 6u, t);  // a2 <= 0x00FF00FF < 2^24
+}
+// horizontal 1-4-6-4-1: a,b = k-2,k+2; c,d = k-1,k+1; e = k
+__device__ __forceinline__ uint32_t horz5(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e)
+{
+    uint32_t t = a + b;
+    t += (c + d + e) << 2;
+    return t + (e << 1);
+}
+
+// same with the outer pair already summed
+__device__ __forceinline__ uint32_t horz5s(uint32_t ab, uint32_t c, uint32_t d, uint32_t e)
+{
+    return ab + ((c + d + e) << 2) + (e << 1);
+}
+
+// 3x3 rect erode/dilate (or identity) on a 4-col x 8-row bit tile; causal in rows (one-row delay).
+// Tile layout: row position p (0 = oldest) at bits 4*(7-p)..+3, column c at bit c of the nibble.
+// `inv` = bits outside the image (neutral for the op).  prev = this stage's previous horizontal result.
+__device__ __forceinline__ uint32_t morph3(uint32_t cur, uint32_t &prev, int kind, uint32_t inv)
+{
+    if (kind == 2) {
+        uint32_t out = alignbit(prev, cur, 4);
+        prev = cur;
+        return out;
+    }
+    const uint32_t km = kind ? 0xFFFFFFFFu : 0u;  // dilate(X) = ~erode(~X)
+    const uint32_t x = (cur ^ km) | inv;
+    const uint32_t xl = from_left(x), xr = from_right(x);
+    const uint32_t l = ((x << 1) & 0xEEEEEEEEu) | ((xl >> 3) & 0x11111111u);
+    const uint32_t r = ((x >> 1) & 0x77777777u) | ((xr << 3) & 0x88888888u);
+    const uint32_t hh = x & l & r;
+    const uint32_t out = hh & alignbit(prev, hh, 4) & alignbit(prev, hh, 8);
+    prev = hh;
+    return out ^ km;
+}
+
+__device__ __forceinline__ uint32_t rows_outside(int y0, int lo, int hi)  // nibble mask of positions with y not in [lo,hi)
+{
+    if (y0 >= lo && y0 + 8 <= hi) return 0u;
+    uint32_t m = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+        if (y0 + p < lo || y0 + p >= hi) m |= 0xFu << (4 * (7 - p));
+    return m;
+}
+
+// the owned bytes of a lane that straddles an ownership boundary (px = address of the lane's pixel 0)
+__device__ __forceinline__ void store_part(u8 *px, uint32_t bytes, uint32_t own)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (own & (1u << k)) px[k] = (u8)(bytes >> (8 * k));
+}
+
+// MODE 0: whole chain (up to two 3x3 ops, moments, final mask).  MODE 1: front end only: the inRange output is
+// written as 0/255 bytes to a.masks (the bit-plane back end, morphbits.hip, runs the morph list and the moments).
+// BAYER: the frames are BayerRG8 mosaics (1 B/px); every fed row loads the three mosaic rows it is interpolated from.
+template <int PRE_K, int POST_K, bool RGB, int NR, int PF, bool M2, int MODE, bool BAYER>
+__global__ __launch_bounds__(256) void k_fused_chain(const Args a)
+{
+    __shared__ int s_tab[512 + 16];
+    s_tab[threadIdx.x] = a.tables[threadIdx.x] * 4;  // 4*sdiv (see hsv_px)
+    s_tab[threadIdx.x + 256] = a.tables[threadIdx.x + 256];
+    if (threadIdx.x < 16)  // nibble -> four mask bytes (bit c -> byte c = 0x00 / 0xFF)
+        s_tab[512 + threadIdx.x] = (int)(((threadIdx.x & 1) ? 0xFFu : 0u) | ((threadIdx.x & 2) ? 0xFF00u : 0u) |
+                                         ((threadIdx.x & 4) ? 0xFF0000u : 0u) | ((threadIdx.x & 8) ? 0xFF000000u : 0u));
+    __syncthreads();
+    const char *tab = reinterpret_cast<const char *>(s_tab);
+
+    const int lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= a.total_items) return;
+    const int strip = item % a.n_strips;
+    const int rest = item / a.n_strips;
+    const int seg = rest % a.n_segs;
+    const int frame = rest / a.n_segs;
+    const int w = a.w, h = a.h;
+    const int ys = seg * a.seg_rows;
+    const int ye = min(ys + a.seg_rows, h);
+    constexpr int HL = BAYER ? 2 : 1;  // halo lanes per side
+    constexpr int SV = strip_valid(BAYER);
+    // Strips are left-aligned (lane columns = 0 mod 4, so the image's left border is a lane boundary) except the last
+    // one when w % 4 != 0: that one is right-aligned (a lane boundary at w).  Every strip is then wrong only within
+    // the blur/morph reach of the border it is NOT aligned to, and never owns columns there (launch_fused).
+    const bool last_strip = strip == a.n_strips - 1;
+    const int base = last_strip ? a.last_base : strip * SV;
+    const int x0 = base - 4 * HL + lane * 4;
+    const int own_lo = last_strip ? a.split_x : strip * SV;
+    const int own_hi = last_strip ? w : min((strip + 1) * SV, a.split_x);
+    const int xl = min(max(x0, 0), w - 4);
+    const bool in_image = x0 >= 0 && x0 < w;
+    uint32_t own = 0;  // bit k: this lane's pixel k is an output of this strip
+    if (lane >= HL && lane <= 63 - HL) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) own |= (x0 + k >= own_lo && x0 + k < own_hi) ? (1u << k) : 0u;
+    }
+    const bool lane_out = own == 0xFu;              // the common case: one dword store per row
+    const bool lane_part = own != 0u && own != 0xFu;  // ownership boundary inside the lane (w % 4 != 0 only)
+    const uint32_t own_rep = own * 0x11111111u;
+    const bool strip_left = strip == 0;
+    const bool strip_right = base + 256 - 4 * HL >= w;
+    const bool lb_halo = x0 == -4, rb_halo = x0 == w;  // halo lanes just outside the left / right image border
+    const uint32_t colinv = in_image ? 0u : 0xFFFFFFFFu;
+
+    // uniform (SGPR) frame pointer + 32-bit per-lane byte offset: loads use the saddr form
+    const u8 *fptr = a.frames + (size_t)frame * a.frame_stride;
+    const uint32_t lane_off = (uint32_t)xl * (BAYER ? 1u : 3u);
+    const bool first_col = x0 == 0, last_col = x0 == w - 4;  // Bayer: the image's border columns copy their neighbours
+    const uint32_t rs = (uint32_t)a.row_stride;  // byte offsets inside one frame fit 32 bits (checked at launch)
+
+    constexpr int LEAD = (POST_K == 5 ? 2 : 0) + (PRE_K == 3 ? 1 : 0);  // rows of look-ahead the blurs need
+    constexpr int MH = MODE == 0 ? 2 : 0;      // row delay of the two morphology stages
+    const int t0 = ys - MH;                    // first inRange row of the tile stream
+    const int r_first = t0 - LEAD;             // first fed row
+    const int n_batches = (ye - ys + 2 * MH + 7) / 8;
+    const bool border_strip = strip_left || strip_right;
+
+    uint32_t raw[8][3];
+    Row ring[8];
+    RowBGR rawp[PRE_K == 3 ? 8 : 1];
+    // raw row in slot `sl` -> HSV row in ring[sl] (with PRE_K == 3: the HSV of the 3x3-blurred row before it)
+    auto bayer_row = [&](int f) { return min(max(reflect_row(r_first + f, h), 1), h - 2); };  // border rows copy too
+    auto convert = [&](int sl, bool have_rows, int f) {
+        Pairs bp;
+        if (BAYER) demosaic_row(raw[sl], bayer_row(f) & 1, border_strip, first_col, last_col, bp);
+        if (PRE_K == 3) {
+            if (BAYER)
+                pairs_to_row(bp, rawp[sl & (PRE_K == 3 ? 7 : 0)]);
+            else
+                unpack_row(raw[sl], rawp[sl & (PRE_K == 3 ? 7 : 0)]);
+            if (have_rows)
+                preblur_hsv_row<RGB>(rawp[(sl + 6) & (PRE_K == 3 ? 7 : 0)], rawp[(sl + 7) & (PRE_K == 3 ? 7 : 0)],
+                                     rawp[sl & (PRE_K == 3 ? 7 : 0)], border_strip, lb_halo, rb_halo, tab, ring[sl]);
+        } else if (BAYER) {
+            hsv_row_pairs(bp, tab, ring[sl]);
+        } else {
+            hsv_row<RGB>(raw[sl], tab, ring[sl]);
+        }
+    };
+    auto load_row = [&](int slot, int f) {
+        if (BAYER) {
+            const uint32_t off = (uint32_t)(bayer_row(f) - 1) * rs + lane_off;
+            raw[slot][0] = *reinterpret_cast<const uint32_t *>(fptr + off);
+            raw[slot][1] = *reinterpret_cast<const uint32_t *>(fptr + off + rs);
+            raw[slot][2] = *reinterpret_cast<const uint32_t *>(fptr + off + 2 * rs);
+        } else {
+            const int r = reflect_row(r_first + f, h);
+            const uint32_t off = (uint32_t)r * rs + lane_off;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(fptr + off);
+            raw[slot][0] = p[0];
+            raw[slot][1] = p[1];
+            raw[slot][2] = p[2];
+        }
+    };
+
+    // fed row f uses raw/ring slot (f + 8 - 2*LEAD) & 7, so that the main step j = f - 2*LEAD uses slot j & 7
+    constexpr int S0 = (8 - 2 * LEAD) & 7;
+#pragma unroll
+    for (int q = 0; q < PF; q++) load_row((S0 + q) & 7, q);
+#pragma unroll
+    for (int q = 0; q < 2 * LEAD; q++) {  // prologue: fill the rings
+        load_row((S0 + q + PF) & 7, q + PF);
+        convert((S0 + q) & 7, q >= (PRE_K == 3 ? 2 : 0), q);
+    }
+
+    uint32_t acc[NR], prev1[NR], prev2[NR];
+    uint32_t m00[NR], m10[NR], m01[NR];
+    unsigned long long m20[NR], m11[NR], m02[NR];  // second-order sums (only with M2)
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = prev1[r] = prev2[r] = m00[r] = m10[r] = m01[r] = 0, m20[r] = m11[r] = m02[r] = 0;
+
+    const size_t plane = (size_t)w * h;
+    u8 *mptr = a.masks ? a.masks + (size_t)frame * a.nr * plane : nullptr;  // uniform
+    const uint32_t mask_off = (uint32_t)max(x0, 0);
+
+    for (int b = 0; b < n_batches; b++) {
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+            const int f = 2 * LEAD + b * 8 + rr;  // fed index of this step's newest row
+            load_row((rr + PF) & 7, f + PF);
+            convert(rr, true, f);
+            uint32_t o_hs[4], o_v[2];
+            if (POST_K == 5) {
+                uint32_t c_hs[4], c_v[2];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    c_hs[k] = vert5(ring[(rr + 4) & 7].hs[k], ring[(rr + 5) & 7].hs[k], ring[(rr + 6) & 7].hs[k],
+                                    ring[(rr + 7) & 7].hs[k], ring[rr].hs[k]);
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    c_v[k] = vert5(ring[(rr + 4) & 7].v[k], ring[(rr + 5) & 7].v[k], ring[(rr + 6) & 7].v[k],
+                                   ring[(rr + 7) & 7].v[k], ring[rr].v[k]);
+                if (border_strip) {
+                    // BORDER_REFLECT_101 at the image's left/right edge: give the halo lane next to the border
+                    // lane the mirrored columns, so the DPP fetches below read col -1 = col 1, col -2 = col 2
+                    // (and col w = col w-2, col w+1 = col w-3).  Those halo lanes never produce output.
+                    const uint32_t m2b = alignbit(c_v[1], c_v[0], 16);  // (V1,V2)
+                    const uint32_t sw = alignbit(m2b, m2b, 16);         // (V2,V1)
+                    const uint32_t a2 = from_right(c_hs[2]), a1 = from_right(c_hs[1]), asw = from_right(sw);
+                    const uint32_t b2 = from_left(c_hs[2]), b1 = from_left(c_hs[1]), bsw = from_left(sw);
+                    if (lb_halo) { c_hs[2] = a2; c_hs[3] = a1; c_v[1] = asw; }
+                    if (rb_halo) { c_hs[0] = b2; c_hs[1] = b1; c_v[0] = bsw; }
+                }
+                const uint32_t l3 = from_left(c_hs[3]), r0 = from_right(c_hs[0]);
+                const uint32_t vl = from_left(c_v[1]), vr = from_right(c_v[0]);
+                const uint32_t m2 = alignbit(c_v[1], c_v[0], 16);  // (V1,V2)
+                // the k-2 / k+2 terms that cross lanes are single-use: written as plain adds so the DPP fetch
+                // folds into the add (v_add_u32_dpp)
+                o_hs[0] = horz5s(add_from_left(c_hs[2], c_hs[2]), l3, c_hs[1], c_hs[0]);
+                o_hs[1] = horz5s(l3 + c_hs[3], c_hs[0], c_hs[2], c_hs[1]);
+                o_hs[2] = horz5s(c_hs[0] + r0, c_hs[1], c_hs[3], c_hs[2]);
+                o_hs[3] = horz5s(add_from_right(c_hs[1], c_hs[1]), c_hs[2], r0, c_hs[3]);
+                const uint32_t m1 = alignbit(c_v[0], vl, 16);  // (V-1,V0)
+                const uint32_t m3 = alignbit(vr, c_v[1], 16);  // (V3,V4)
+                o_v[0] = horz5s(vl + c_v[1], m1, m2, c_v[0]);
+                o_v[1] = horz5s(c_v[0] + vr, m2, m3, c_v[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) o_hs[k] = ring[rr].hs[k];
+                o_v[0] = ring[rr].v[0];
+                o_v[1] = ring[rr].v[1];
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
+                const uint32_t vlo = a.v_lo[r], vhi = a.v_hi[r];
+                uint32_t t = acc[r];
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const uint32_t vk = (k & 1) ? (o_v[k >> 1] >> 16) : (o_v[k >> 1] & 0xFFFFu);
+                    // three compares write lane masks; the AND is scalar work
+                    const unsigned long long ok = __builtin_amdgcn_ballot_w64(pk_clamp(o_hs[k], a.hs_lo[r], a.hs_hi[r]) == o_hs[k]) &
+                                                  __builtin_amdgcn_ballot_w64(vk >= vlo) & __builtin_amdgcn_ballot_w64(vk <= vhi);
+                    t = shift_in(t, ok);
+                }
+                acc[r] = t;
+            }
+        }
+        const int yt = t0 + b * 8;  // image row of tile position 0 at the inRange stage
+        if (MODE == 1) {
+            // ---- front end only: the inRange rows go out as 0/255 bytes ----
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
+                const uint32_t t = acc[r];
+                u8 *rowp = mptr + (size_t)r * plane + (size_t)yt * w;  // uniform
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    const int y = yt + p;
+                    if (y >= ys && y < ye && (lane_out || lane_part)) {
+                        const int sh = 4 * (7 - p) - 2;
+                        const uint32_t idx = (sh >= 0 ? (t >> sh) : (t << 2)) & 0x3Cu;
+                        const uint32_t bytes = *reinterpret_cast<const uint32_t *>(tab + 2048 + idx);
+                        if (lane_out)
+                            *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = bytes;
+                        else
+                            store_part(rowp + ((long long)p * w + x0), bytes, own);
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- one 4x8 tile per range is complete: morphology, store, moments ----
+        const uint32_t inv1 = colinv | rows_outside(yt, 0, h);
+        const uint32_t inv2 = colinv | rows_outside(yt - 1, 0, h);
+        const uint32_t keep = own_rep & ~rows_outside(yt - 2, ys, ye);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
+            uint32_t t = morph3(acc[r], prev1[r], a.op0, inv1);
+            t = morph3(t, prev2[r], a.op1, inv2);
+            const uint32_t fm = t & keep;
+            if (mptr) {
+                // tile row p -> nibble*4 -> LDS lookup of the four mask bytes (two VALU ops + one ds_read per row)
+                auto expand = [&](uint32_t tile, int p) {
+                    const int sh = 4 * (7 - p) - 2;
+                    const uint32_t idx = (sh >= 0 ? (tile >> sh) : (tile << 2)) & 0x3Cu;
+                    return *reinterpret_cast<const uint32_t *>(tab + 2048 + idx);
+                };
+                u8 *rowp = mptr + (size_t)r * plane + (size_t)(yt - 2) * w;  // uniform
+                if (yt - 2 >= ys && yt - 2 + 8 <= ye) {  // whole tile inside the segment (the common case)
+                    if (lane_out) {
+#pragma unroll
+                        for (int p = 0; p < 8; p++)
+                            *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = expand(t, p);
+                    } else if (lane_part) {
+#pragma unroll
+                        for (int p = 0; p < 8; p++) store_part(rowp + ((long long)p * w + x0), expand(t, p), own);
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 8; p++) {
+                        const int y = yt - 2 + p;
+                        if (y >= ys && y < ye && lane_out)
+                            *reinterpret_cast<uint32_t *>(rowp + (size_t)p * w + mask_off) = expand(t, p);
+                        else if (y >= ys && y < ye && lane_part)
+                            store_part(rowp + ((long long)p * w + x0), expand(t, p), own);
+                    }
+                }
+            }
+            const uint32_t cnt = __popc(fm);
+            const uint32_t csum = __popc(fm & 0xAAAAAAAAu) + 2 * __popc(fm & 0xCCCCCCCCu);
+            const uint32_t q = __popc(fm & 0xF0F0F0F0u) + 2 * __popc(fm & 0xFF00FF00u) + 4 * __popc(fm & 0xFFFF0000u);
+            m00[r] += cnt;
+            m10[r] = mad_u24((uint32_t)x0, cnt, m10[r]) + csum;   // x0 < 2^24 wherever cnt != 0
+            m01[r] = mad_u24((uint32_t)(yt + 5), cnt, m01[r]) - q;  // sum of rows = (yt-2+7)*cnt - q; yt+5 > 0 wherever cnt != 0
+            if (M2 && __builtin_amdgcn_ballot_w64(fm != 0)) {
+                // x = x0 + c (c = bit & 3), y = Y7 - u (u = bit >> 2): all second-order sums from popcounts of the tile
+                const uint32_t CA = 0xAAAAAAAAu, CB = 0xCCCCCCCCu, U0 = 0xF0F0F0F0u, U1 = 0xFF00FF00u, U2 = 0xFFFF0000u;
+                const uint32_t c2 = __popc(fm & CA) + 4 * __popc(fm & CB) + 4 * __popc(fm & CA & CB);              // sum c^2
+                const uint32_t u2 = __popc(fm & U0) + 4 * __popc(fm & U1) + 16 * __popc(fm & U2) +
+                                    4 * __popc(fm & U0 & U1) + 8 * __popc(fm & U0 & U2) + 16 * __popc(fm & U1 & U2);  // sum u^2
+                const uint32_t cu = __popc(fm & CA & U0) + 2 * __popc(fm & CA & U1) + 4 * __popc(fm & CA & U2) +
+                                    2 * __popc(fm & CB & U0) + 4 * __popc(fm & CB & U1) + 8 * __popc(fm & CB & U2);   // sum c*u
+                const unsigned long long X = (unsigned long long)(uint32_t)max(x0, 0), Y7 = (unsigned long long)(uint32_t)max(yt + 5, 0);
+                const unsigned long long sy = Y7 * cnt - q;      // sum y
+                const unsigned long long scy = Y7 * csum - cu;   // sum c*y
+                m20[r] += X * X * cnt + 2 * X * csum + c2;
+                m11[r] += X * sy + scy;
+                m02[r] += Y7 * Y7 * cnt + u2 - 2 * Y7 * q;
+            }
+        }
+    }
+
+    if (MODE == 1) return;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
+        unsigned long long s0 = m00[r], s1 = m10[r], s2 = m01[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_down(s0, off, 64);
+            s1 += __shfl_down(s1, off, 64);
+            s2 += __shfl_down(s2, off, 64);
+        }
+        if (lane == 0) {
+            unsigned long long *o = a.mom + ((size_t)frame * a.nr + r) * 6;
+            if (s0) {
+                atomicAdd(o + 0, s0);
+                atomicAdd(o + 1, s1);
+                atomicAdd(o + 2, s2);
+            }
+        }
+        if (M2) {
+            unsigned long long t0 = m20[r], t1 = m11[r], t2 = m02[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                t0 += __shfl_down(t0, off, 64);
+                t1 += __shfl_down(t1, off, 64);
+                t2 += __shfl_down(t2, off, 64);
+            }
+            if (lane == 0 && s0) {
+                unsigned long long *o = a.mom + ((size_t)frame * a.nr + r) * 6;
+                atomicAdd(o + 3, t0);
+                atomicAdd(o + 4, t1);
+                atomicAdd(o + 5, t2);
+            }
+        }
+    }
+}
+
+
+// One translation unit per group of instantiations (the build compiles them in parallel): Bayer or not, small (1, 2)
+// or large (4, 8) range capacity.  Each dispatches on (pre_k, post_k, rgb, nr capacity, second order, mode).
+struct Variant {
+    int pre_k, post_k, rgb, cap, second_order, mode;
+};
+hipError_t launch_variant_plain_small(const Variant &v, const Args &a, dim3 grid, hipStream_t stream);
+hipError_t launch_variant_plain_large(const Variant &v, const Args &a, dim3 grid, hipStream_t stream);
+hipError_t launch_variant_bayer_small(const Variant &v, const Args &a, dim3 grid, hipStream_t stream);
+hipError_t launch_variant_bayer_large(const Variant &v, const Args &a, dim3 grid, hipStream_t stream);
+
+// body shared by the four: NRA / NRB are the two capacities of the group
+#define IPF_DEFINE_LAUNCH_VARIANT(NAME, BAYERV, NRA, NRB)                                                              \
+    hipError_t NAME(const Variant &v, const Args &a, dim3 grid, hipStream_t stream)                                    \
+    {                                                                                                                   \
+        const dim3 block(256);                                                                                          \
+        auto go = [&](auto pre, auto post, auto rgb, auto cap) {                                                        \
+            constexpr int PRE = decltype(pre)::value, POST = decltype(post)::value, CAP = decltype(cap)::value;         \
+            constexpr bool RGBV = decltype(rgb)::value;                                                                 \
+            if (v.mode == 1)                                                                                            \
+                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, 3, false, 1, BAYERV>), grid, block, 0, stream, a); \
+            else if (v.second_order)                                                                                    \
+                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, 3, true, 0, BAYERV>), grid, block, 0, stream, a);  \
+            else                                                                                                        \
+                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, 3, false, 0, BAYERV>), grid, block, 0, stream, a); \
+        };                                                                                                              \
+        using std::integral_constant;                                                                                   \
+        auto with_cap = [&](auto pre, auto post, auto rgb) {                                                            \
+            if (v.cap == NRA) go(pre, post, rgb, integral_constant<int, NRA>{});                                        \
+            else go(pre, post, rgb, integral_constant<int, NRB>{});                                                     \
+        };                                                                                                              \
+        auto with_rgb = [&](auto pre, auto post) {                                                                      \
+            if (!BAYERV && v.rgb) with_cap(pre, post, integral_constant<bool, !BAYERV>{});                              \
+            else with_cap(pre, post, integral_constant<bool, false>{});                                                 \
+        };                                                                                                              \
+        if (v.pre_k == 3) {                                                                                             \
+            if (v.post_k == 5) with_rgb(integral_constant<int, 3>{}, integral_constant<int, 5>{});                      \
+            else with_rgb(integral_constant<int, 3>{}, integral_constant<int, 1>{});                                    \
+        } else {                                                                                                        \
+            if (v.post_k == 5) with_rgb(integral_constant<int, 1>{}, integral_constant<int, 5>{});                      \
+            else with_rgb(integral_constant<int, 1>{}, integral_constant<int, 1>{});                                    \
+        }                                                                                                               \
+        return hipGetLastError();                                                                                       \
+    }
+
+}  // namespace ipf

@@ -1,5 +1,5 @@
 """Device-resident batch throughput of the reference's other chains (not the headline config of bench.py).
-usage: python scripts/preset_bench.py [preset ...]   presets: baseline polygon_path pose_estimate pose_estimate_full c1"""
+usage: python scripts/preset_bench.py [preset ...]   presets: baseline polygon_path pose_estimate pose_estimate_full c1 baseline_8r"""
 import os
 import sys
 import time
@@ -13,17 +13,19 @@ from image_processing_amd.synth import DEFAULT_RANGE, synth_batch
 
 P = {"pose_estimate": dict(), "pose_estimate_full": dict(post_blur_k=5, morph=ip.MORPH_POSE_ESTIMATE),
      "baseline": dict(post_blur_k=5, morph=ip.MORPH_BASELINE), "c1": dict(morph=ip.MORPH_BASELINE),
-     "polygon_path": dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH)}
+     "polygon_path": dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH),
+     "baseline_8r": dict(post_blur_k=5, morph=ip.MORPH_BASELINE)}  # eight hue bands in one launch (capacity-8 variant)
+R8 = [((20 * i, 60, 60), (20 * i + 19, 256, 256)) for i in range(8)]
 w, h, n = 1920, 1200, 64
 frames = synth_batch(w, h, n, unique=4)
 with ip.ImgProc(w, h, n_slots=1, max_batch=n) as g:
     d_in = g.dev_alloc(frames.nbytes)
-    d_out = g.dev_alloc(n * w * h)
+    d_out = g.dev_alloc(8 * n * w * h)
     g.dev_upload(d_in, frames)
     raw = (L.Result * n)()
     for name in (sys.argv[1:] or list(P)):
         g.set_pipeline(**P[name])
-        g.set_ranges([DEFAULT_RANGE])
+        g.set_ranges(R8 if name.endswith("_8r") else [DEFAULT_RANGE])
         g.set_profiling(True)
         for _ in range(2):
             g.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, d_out, raw=raw)

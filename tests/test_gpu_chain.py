@@ -455,3 +455,40 @@ def test_odd_widths_stay_on_the_fast_path(gpu, oracle, w, preset):
             assert (masks[i] == exp["mask"][0]).all(), (w, preset, enc, i)
             check_moments(res[i][0], exp["moments"][0], second=True)
     gpu.set_profiling(False)
+
+
+@pytest.mark.parametrize("nr", [3, 4, 5, 8])
+@pytest.mark.parametrize("preset", ["baseline", "polygon_path"])
+def test_up_to_eight_ranges_in_one_launch(gpu, oracle, nr, preset):
+    """3..8 ranges (imgproc_set_ranges takes 1..8) run in the capacity-4 / capacity-8 variants of the chain kernel."""
+    h, w, n = 70, 500, 2
+    kw = PRESETS[preset]
+    frames = synth_batch(w, h, n, seed=77, hue_bands=tuple((20 * i, 20 * i + 19) for i in range(nr)))
+    ranges = [((20 * i, 60, 60), (20 * i + 19, 256, 256)) for i in range(nr)]
+    ranges[-1] = ((200, 0, 0), (100, 256, 256))  # an empty H interval: never matches
+    gpu.set_pipeline(second_order=True, **kw)
+    gpu.set_ranges(ranges)
+    gpu.set_profiling(True)
+    d_in, d_out = gpu.dev_alloc(frames.nbytes), gpu.dev_alloc(n * nr * w * h)
+    try:
+        gpu.dev_upload(d_in, frames)
+        res = gpu.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, d_out)
+        assert gpu.last_kernel_ms()[1] == (1 if preset == "baseline" else 2)
+        masks = gpu.dev_download(d_out, (n, nr, h, w))
+    finally:
+        gpu.dev_free(d_in)
+        gpu.dev_free(d_out)
+        gpu.set_profiling(False)
+    for i in range(n):
+        exp = oracle.chain(frames[i], pre_blur_k=kw["pre_blur_k"], post_blur_k=kw["post_blur_k"],
+                           morph=morph_tuples(kw["morph"]), ranges=ranges, stages=False)
+        for r in range(nr):
+            assert (masks[i, r] == exp["mask"][r]).all(), (nr, preset, i, r)
+            check_moments(res[i][r], exp["moments"][r], second=True)
+        assert exp["moments"][nr - 1][0] == 0 and (preset != "baseline" or sum(int(m[0]) for m in exp["moments"]) > 0)
+    res1 = gpu.process(frames[0])  # the streaming path takes the same variants
+    exp = oracle.chain(frames[0], pre_blur_k=kw["pre_blur_k"], post_blur_k=kw["post_blur_k"], morph=morph_tuples(kw["morph"]),
+                       ranges=ranges, stages=False)
+    for r in range(nr):
+        assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all()
+        check_moments(res1[r], exp["moments"][r], second=True)
