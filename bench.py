@@ -192,7 +192,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(base_np, 4 * threads, threads)
+            out["cpu_baseline"] = cpu_baseline(base_np, 8 * threads, threads)
         print(json.dumps(out), flush=True)
     g.close()
     if dist is not None:
