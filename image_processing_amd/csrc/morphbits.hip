@@ -202,10 +202,14 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
             m[1] += sx;
             m[2] += (unsigned long long)y * cnt;
             if (a.second_order) {
-                unsigned long long bs2 = 0;  // sum of squared bit indices
-                for (uint32_t b = bits; b; b &= b - 1) {
-                    const unsigned i = __ffs(b) - 1;
-                    bs2 += i * i;
+                // sum of squared bit indices i = sum_j 2^j b_j(i): i^2 = sum_j 4^j b_j + sum_{j<k} 2^(j+k+1) b_j b_k
+                const uint32_t B[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
+                unsigned long long bs2 = 0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    bs2 += (unsigned long long)__popc(bits & B[j]) << (2 * j);
+#pragma unroll
+                    for (int k = j + 1; k < 5; k++) bs2 += (unsigned long long)__popc(bits & B[j] & B[k]) << (j + k + 1);
                 }
                 m[3] += (unsigned long long)x0 * x0 * cnt + 2ull * x0 * bs + bs2;
                 m[4] += (unsigned long long)y * sx;
