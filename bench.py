@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 W, H, BATCH = 1920, 1200, 256
 ALGO_BYTES_PER_FRAME = W * H * 4  # 3 B/px read + 1 B/px mask written
+PREROLL_S = 0.15  # untimed steady-state pre-roll before the warmup steps (GPU clock ramp)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -56,8 +57,8 @@ def cpu_baseline(frames: np.ndarray, n_frames: int, threads: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")
     ap.add_argument("--check", action="store_true", help="also verify one frame of the batch against the oracle")
@@ -120,6 +121,12 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
 
+    # The GPU's clocks take tens of milliseconds of sustained load to settle (measured: the same kernel runs 0.87 ms in
+    # a 23-step run and 0.78 ms from the ~40th step on).  The metric is steady-state throughput, so the device is kept
+    # busy with the same step for PREROLL_S before the W warmup steps; nothing of it is timed or reported.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PREROLL_S:
+        step()
     for _ in range(args.warmup):
         res = step()
     fence()
@@ -180,7 +187,7 @@ def main() -> None:
             "config": {"workload": "configs[1]: 1920x1200 BGR8, device-resident batch of 256 frames per GPU per step, "
                                    "post-HSV 5x5 Gaussian + inRange + erode3 + dilate3 + moments, masks written to HBM; "
                                    "two steps in flight (results of step i are collected after step i+1 is enqueued)",
-                       "frames_per_step_per_gpu": BATCH, "width": W, "height": H,
+                       "frames_per_step_per_gpu": BATCH, "width": W, "height": H, "untimed_preroll_s": PREROLL_S,
                        "path": "fused" if fused else f"stage-by-stage ({launches} launches per step)",
                        "sharding": f"frames x{world} ranks, no collective; {BATCH * world} centroids gathered on rank 0 "
                                    f"after the timed region ({n_found} with an object)"},
