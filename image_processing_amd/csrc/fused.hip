@@ -114,7 +114,7 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     const int nr = plan.bounds.n;
     const int sh = plan.post_k == 5 ? 8 : 0;  // blurred fields are 8.8
     for (int r = 0; r < MAX_NR; r++) {  // ranges beyond nr (spare capacity of the 4 / 8 variants) never match
-        a.hs_lo[r] = 0; a.hs_hi[r] = 0xFFFFFFFFu; a.v_lo[r] = 0xFFFFu; a.v_hi[r] = 0;
+        a.hs_lo[r] = 0; a.hs_hi[r] = 0xFFFFFFFFu; a.v_lo[r] = 0xFFFFFFFFu; a.v_hi[r] = 0;
     }
     for (int r = 0; r < nr; r++) {
         const auto &B = plan.bounds;
@@ -125,13 +125,13 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
         if (never) {  // an empty channel interval empties the whole mask: make the V test unsatisfiable
             a.hs_lo[r] = 0;
             a.hs_hi[r] = 0xFFFFFFFFu;
-            a.v_lo[r] = 0xFFFFu;
+            a.v_lo[r] = 0xFFFFFFFFu;  // no V field is ever 0xFFFF (8.8 fields stop at 255 * 256 + 128)
             a.v_hi[r] = 0;
         } else {
             a.hs_lo[r] = lo16(0) | (lo16(1) << 16);
             a.hs_hi[r] = hi16(0) | (hi16(1) << 16);
-            a.v_lo[r] = lo16(2);
-            a.v_hi[r] = hi16(2);
+            a.v_lo[r] = lo16(2) | (lo16(2) << 16);
+            a.v_hi[r] = hi16(2) - lo16(2);
         }
     }
     Variant v{};

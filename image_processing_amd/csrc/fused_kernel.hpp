@@ -47,7 +47,8 @@ struct Args {
     int last_base;  // first valid column of the last strip: (n_strips-1)*SV, or w - SV (right-aligned) when w % 4 != 0
     int split_x;    // the last strip owns columns >= split_x, the others own [strip*SV, min((strip+1)*SV, split_x))
     int op0, op1;  // 0 erode3, 1 dilate3, 2 identity (one-row delay only)
-    uint32_t hs_lo[MAX_NR], hs_hi[MAX_NR], v_lo[MAX_NR], v_hi[MAX_NR];
+    uint32_t hs_lo[MAX_NR], hs_hi[MAX_NR];  // H | S << 16 bounds (8.8 fields after the 5x5 blur)
+    uint32_t v_lo[MAX_NR], v_hi[MAX_NR];    // V: (lo | lo << 16) and hi - lo; lo = 0xFFFF with hi - lo = 0 never matches
 };
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -520,14 +521,18 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
-                const uint32_t vlo = a.v_lo[r], vhi = a.v_hi[r];
+                // V: (v - lo) <= (hi - lo) as unsigned 16-bit fields: one packed subtract per pair, one compare per pixel
+                const uint32_t vlo2 = a.v_lo[r], vrng = a.v_hi[r];  // (lo | lo << 16), hi - lo
+                uint32_t dv[2];
+                asm("v_pk_sub_u16 %0, %1, %2" : "=v"(dv[0]) : "v"(o_v[0]), "s"(vlo2));
+                asm("v_pk_sub_u16 %0, %1, %2" : "=v"(dv[1]) : "v"(o_v[1]), "s"(vlo2));
                 uint32_t t = acc[r];
 #pragma unroll
                 for (int k = 3; k >= 0; k--) {
-                    const uint32_t vk = (k & 1) ? (o_v[k >> 1] >> 16) : (o_v[k >> 1] & 0xFFFFu);
-                    // three compares write lane masks; the AND is scalar work
+                    const uint32_t vk = (k & 1) ? (dv[k >> 1] >> 16) : (dv[k >> 1] & 0xFFFFu);
+                    // two compares write lane masks; the AND is scalar work
                     const unsigned long long ok = __builtin_amdgcn_ballot_w64(pk_clamp(o_hs[k], a.hs_lo[r], a.hs_hi[r]) == o_hs[k]) &
-                                                  __builtin_amdgcn_ballot_w64(vk >= vlo) & __builtin_amdgcn_ballot_w64(vk <= vhi);
+                                                  __builtin_amdgcn_ballot_w64(vk <= vrng);
                     t = shift_in(t, ok);
                 }
                 acc[r] = t;
@@ -659,6 +664,10 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 
 // One translation unit per group of instantiations (the build compiles them in parallel): Bayer or not, small (1, 2)
 // or large (4, 8) range capacity.  Each dispatches on (pre_k, post_k, rgb, nr capacity, second order, mode).
+#ifndef IPF_PF
+#define IPF_PF 3  // rows of raw-load prefetch ahead of the row being converted
+#endif
+
 struct Variant {
     int pre_k, post_k, rgb, cap, second_order, mode;
 };
@@ -676,11 +685,11 @@ hipError_t launch_variant_bayer_large(const Variant &v, const Args &a, dim3 grid
             constexpr int PRE = decltype(pre)::value, POST = decltype(post)::value, CAP = decltype(cap)::value;         \
             constexpr bool RGBV = decltype(rgb)::value;                                                                 \
             if (v.mode == 1)                                                                                            \
-                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, 3, false, 1, BAYERV>), grid, block, 0, stream, a); \
+                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, false, 1, BAYERV>), grid, block, 0, stream, a); \
             else if (v.second_order)                                                                                    \
-                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, 3, true, 0, BAYERV>), grid, block, 0, stream, a);  \
+                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, true, 0, BAYERV>), grid, block, 0, stream, a);  \
             else                                                                                                        \
-                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, 3, false, 0, BAYERV>), grid, block, 0, stream, a); \
+                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, false, 0, BAYERV>), grid, block, 0, stream, a); \
         };                                                                                                              \
         using std::integral_constant;                                                                                   \
         auto with_cap = [&](auto pre, auto post, auto rgb) {                                                            \
