@@ -152,15 +152,32 @@ struct Row {  // one row of this lane's 4 pixels as packed 16-bit fields
     uint32_t v[2];   // (V0,V1), (V2,V3)
 };
 
+// byte B of w, times 4, in one SDWA shift (the compiler spends two ops on byte 0)
+template <int B>
+__device__ __forceinline__ uint32_t byte_x4(uint32_t w)
+{
+    uint32_t r;
+    const uint32_t two = 2u;
+    if (B == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+    else if (B == 1)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
+    else if (B == 2)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
+
 template <bool RGB>
 __device__ __forceinline__ void hsv_row(const uint32_t (&w)[3], const char *tab, Row &o)
 {
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
     uint32_t vv[4];
-    hsv_px<RGB>((w0 & 0xFF) << 2, ((w0 >> 8) & 0xFF) << 2, ((w0 >> 16) & 0xFF) << 2, tab, o.hs[0], vv[0]);
-    hsv_px<RGB>((w0 >> 24) << 2, (w1 & 0xFF) << 2, ((w1 >> 8) & 0xFF) << 2, tab, o.hs[1], vv[1]);
-    hsv_px<RGB>(((w1 >> 16) & 0xFF) << 2, (w1 >> 24) << 2, (w2 & 0xFF) << 2, tab, o.hs[2], vv[2]);
-    hsv_px<RGB>(((w2 >> 8) & 0xFF) << 2, ((w2 >> 16) & 0xFF) << 2, (w2 >> 24) << 2, tab, o.hs[3], vv[3]);
+    hsv_px<RGB>(byte_x4<0>(w0), byte_x4<1>(w0), byte_x4<2>(w0), tab, o.hs[0], vv[0]);
+    hsv_px<RGB>(byte_x4<3>(w0), byte_x4<0>(w1), byte_x4<1>(w1), tab, o.hs[1], vv[1]);
+    hsv_px<RGB>(byte_x4<2>(w1), byte_x4<3>(w1), byte_x4<0>(w2), tab, o.hs[2], vv[2]);
+    hsv_px<RGB>(byte_x4<1>(w2), byte_x4<2>(w2), byte_x4<3>(w2), tab, o.hs[3], vv[3]);
     o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;  // 4*V0 is a multiple of 4: no bits cross the field boundary
     o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
 }
