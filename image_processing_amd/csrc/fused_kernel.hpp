@@ -127,7 +127,8 @@ __device__ __forceinline__ int reflect_row(int r, int h)
 }
 
 // One pixel of cvtColor(BGR2HSV).  Inputs are the channel bytes times 4 (they double as
-// byte offsets into the LDS reciprocal tables); (d*4*sdiv + 2^13) >> 14 == (d*sdiv + 2^11) >> 12.
+// byte offsets into the LDS reciprocal tables, which hold 4*sdiv and 4*hdiv180);
+// (4hh * 4hdiv + 2^15) >> 16 == (hh*hdiv + 2^11) >> 12, so H lands in byte 2 of the product like S does.
 template <bool RGB>
 __device__ __forceinline__ void hsv_px(uint32_t c0, uint32_t c1, uint32_t c2, const char *tab, uint32_t &hs,
                                        uint32_t &v)
@@ -135,15 +136,15 @@ __device__ __forceinline__ void hsv_px(uint32_t c0, uint32_t c1, uint32_t c2, co
     const int b4 = RGB ? c2 : c0, g4 = c1, r4 = RGB ? c0 : c2;
     const int v4 = max3u(b4, g4, r4), m4 = min3u(b4, g4, r4), d4 = v4 - m4;
     const int sdiv4 = *reinterpret_cast<const int *>(tab + v4);        // 4 * sdiv[v]
-    const int hdiv = *reinterpret_cast<const int *>(tab + 1024 + d4);  // hdiv180[diff]
+    const int hdiv4 = *reinterpret_cast<const int *>(tab + 1024 + d4);  // 4 * hdiv180[diff]
     // S << 16 == ((d*sdiv + 2^11) >> 12) << 16 == (4d * 4sdiv + 2^15) & 0xFFFF0000   (4d*4sdiv <= 2^24)
-    const uint32_t s16 = mad_u24((uint32_t)d4, (uint32_t)sdiv4, 32768u) & 0xFFFF0000u;
+    const uint32_t s16 = mad_u24((uint32_t)d4, (uint32_t)sdiv4, 32768u);  // S in byte 2, byte 3 = 0
     int hr = g4 - b4, hg = (b4 - r4) + 2 * d4, hb = (r4 - g4) + 4 * d4;
     asm("" : "+v"(hr), "+v"(hg), "+v"(hb));  // keep the three candidates live: selects, not branches
     const int hh = (v4 == r4) ? hr : (v4 == g4) ? hg : hb;
-    const int x = mad_i24(hh, hdiv, 8192);
-    const int h = mad_i24(x >> 31, -180, x >> 14);  // (x >> 14) + (x < 0 ? 180 : 0)
-    hs = (uint32_t)h | s16;
+    const uint32_t x = (uint32_t)mad_i24(hh, hdiv4, 32768);  // |4hh * 4hdiv| <= 180 << 16
+    const uint32_t xw = min(x, x + (180u << 16));              // negative hue: + 180 (as unsigned, the wrapped sum is the smaller)
+    hs = __builtin_amdgcn_perm(s16, xw, 0x07060C02u);          // H = byte 2 of xw -> byte 0; S = byte 2 of s16 stays
     v = (uint32_t)v4;  // still times 4; hsv_row unscales a packed pair with one shift
 }
 
@@ -325,7 +326,11 @@ __device__ __forceinline__ uint32_t horz5(uint32_t a, uint32_t b, uint32_t c, ui
 // same with the outer pair already summed
 __device__ __forceinline__ uint32_t horz5s(uint32_t ab, uint32_t c, uint32_t d, uint32_t e)
 {
-    return ab + ((c + d + e) << 2) + (e << 1);
+    uint32_t t, u, r;  // ab + 4(c+d+e) + 2e in three ops (the compiler's own choice takes four)
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(c), "v"(d), "v"(e));
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(u) : "v"(e), "v"(ab));
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(t), "v"(u));
+    return r;
 }
 
 // 3x3 rect erode/dilate (or identity) on a 4-col x 8-row bit tile; causal in rows (one-row delay).
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 {
     __shared__ int s_tab[512 + 16];
     s_tab[threadIdx.x] = a.tables[threadIdx.x] * 4;  // 4*sdiv (see hsv_px)
-    s_tab[threadIdx.x + 256] = a.tables[threadIdx.x + 256];
+    s_tab[threadIdx.x + 256] = a.tables[threadIdx.x + 256] * 4;  // 4*hdiv180
     if (threadIdx.x < 16)  // nibble -> four mask bytes (bit c -> byte c = 0x00 / 0xFF)
         s_tab[512 + threadIdx.x] = (int)(((threadIdx.x & 1) ? 0xFFu : 0u) | ((threadIdx.x & 2) ? 0xFF00u : 0u) |
                                          ((threadIdx.x & 4) ? 0xFF0000u : 0u) | ((threadIdx.x & 8) ? 0xFF000000u : 0u));
@@ -428,7 +433,8 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const int t0 = ys - MH;                    // first inRange row of the tile stream
     const int r_first = t0 - LEAD;             // first fed row
     const int n_batches = (ye - ys + 2 * MH + 7) / 8;
-    const bool border_strip = strip_left || strip_right;
+    // kept as a scalar integer: as a bool the compiler re-materialises it through a VGPR on every row
+    const bool border_strip = __builtin_amdgcn_readfirstlane((int)(strip_left || strip_right)) != 0;
 
     uint32_t raw[8][3];
     Row ring[8];
