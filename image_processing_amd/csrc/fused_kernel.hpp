@@ -203,7 +203,7 @@ __device__ __forceinline__ void unpack_row(const uint32_t (&w)[3], RowBGR &o)
 // 1-2-1 passes (the +8 is the folded rounding: +2 per field in the vertical pass times the horizontal weight 4), so the
 // channel value times 4 that hsv_px wants is (field >> 2) & 0x3FC.
 template <bool RGB>
-__device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &r1, const RowBGR &r2, bool border_strip,
+__device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &r1, const RowBGR &r2, int border_strip,
                                                 bool lb_halo, bool rb_halo, const char *tab, Row &o)
 {
     uint32_t v[4], u[2];
@@ -246,7 +246,7 @@ struct Pairs {
     uint32_t b[2], g[2], r[2];
 };
 
-__device__ __forceinline__ void demosaic_row(const uint32_t (&w)[3], bool odd_row, bool border_strip, bool first_col,
+__device__ __forceinline__ void demosaic_row(const uint32_t (&w)[3], bool odd_row, int border_strip, bool first_col,
                                              bool last_col, Pairs &o)
 {
     const uint32_t M8 = 0x00FF00FFu;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const int r_first = t0 - LEAD;             // first fed row
     const int n_batches = (ye - ys + 2 * MH + 7) / 8;
     // kept as a scalar integer: as a bool the compiler re-materialises it through a VGPR on every row
-    const bool border_strip = __builtin_amdgcn_readfirstlane((int)(strip_left || strip_right)) != 0;
+    const int border_strip = __builtin_amdgcn_readfirstlane((int)(strip_left || strip_right));  // int, not bool: see above
 
     uint32_t raw[8][3];
     Row ring[8];
