@@ -175,7 +175,7 @@ def main() -> None:
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
         # --pmc runs of this same command, gfx950 x2 correction on the read side); null when the file is absent
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_e_traffic.json")
         if fused and os.path.exists(tpath):
             with open(tpath) as tf:
                 traffic = json.load(tf).get("hbm_bytes_per_launch")
