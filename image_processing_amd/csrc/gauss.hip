@@ -4,8 +4,9 @@
 // One wave owns a 512-byte column strip of the interleaved image (8 bytes per lane; the outer lanes are halo) and
 // marches down a segment of rows.  The last K raw rows live in a register ring as 16-bit byte pairs, so the column
 // pass is SWAR: one v_mad_u32_u24 per two bytes and tap (partial sums stay below 2^16 because the taps sum to 256).
-// Its 8.8 result row goes through a 1 KB per-wave LDS row, the row pass reads it back as aligned b128 windows and forms t_i*(x[-i]+x[+i]) with SDWA word selects -- no byte extraction, no division, no
-// barrier (LDS ops of one wave execute in order).  OpenCV's single rounding (sum + 2^15) >> 16 is folded in as +128 per
+// Its 8.8 result row goes through a 1 KB per-wave LDS row, the row pass reads it back as aligned b128 windows and
+// forms t_i*(x[-i]+x[+i]) with SDWA word selects -- no byte extraction, no division, no barrier (LDS ops of one wave
+// execute in order).  OpenCV's single rounding (sum + 2^15) >> 16 is folded in as +128 per
 // 8.8 field of the column pass (256 * 128 = 2^15).  Arithmetic: SURVEY.md Appendix A.2; the generic tile kernel in
 // kernels.hip remains for k > 15, unsymmetric taps and unaligned rows.
 #include "kernels.h"
