@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
 {
     __shared__ uint32_t s_a[N_WORDS_MAX];
     __shared__ uint32_t s_b[N_WORDS_MAX];
-    __shared__ uint32_t s_inv[N_WORDS_MAX];  // bits outside the image (neutral for every op: OpenCV's morphologyDefaultBorderValue)
+    // bits outside the image (neutral for every op: OpenCV's morphologyDefaultBorderValue) = row part | column part
+    __shared__ uint32_t s_rinv[LH_MAX], s_cinv[LW_MAX];
     __shared__ unsigned long long s_red[4][6];
 
     const int tid = threadIdx.x;
@@ -95,6 +96,17 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
     const bool vec = true;  // dword accesses may be unaligned (w % 4 != 0): fine for gfx950 global memory (scripts/ubench/unaligned.hip)
     auto mask_of = [](int kind) { return kind ? 0xFFFFFFFFu : 0u; };  // dilate(X) = ~erode(~X)
 
+    if (tid < LH) s_rinv[tid] = (y_org + tid >= 0 && y_org + tid < h) ? 0u : 0xFFFFFFFFu;
+    if (tid < LW) {
+        const int x0 = x_org + tid * 32;
+        uint32_t inv = 0xFFFFFFFFu;
+        if (x0 < w && x0 + 32 > 0) {
+            inv = 0;
+            if (x0 < 0) inv |= (1u << (-x0)) - 1u;             // x0 in (-32, 0)
+            if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);  // partially beyond the right edge
+        }
+        s_cinv[tid] = inv;
+    }
     // ---- pack: one 32-px word per thread-iteration, stored in the first group's erode domain ----
     const uint32_t km_first = mask_of(a.groups[0].kind);
     for (int idx = tid; idx < LH * LW; idx += 256) {
@@ -103,8 +115,8 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
         uint32_t bits = 0, inv = 0xFFFFFFFFu;
         if (y >= 0 && y < h && x0 < w && x0 + 32 > 0) {
             inv = 0;
-            if (x0 < 0) inv |= (1u << (-x0)) - 1u;             // x0 in (-32, 0)
-            if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);  // partially beyond the right edge
+            if (x0 < 0) inv |= (1u << (-x0)) - 1u;
+            if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);
             const u8 *row = src + (size_t)y * w;
             if (vec && x0 >= 0 && x0 + 32 <= w) {
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x0);
@@ -115,7 +127,6 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
                     if (x0 + i >= 0 && x0 + i < w && row[x0 + i]) bits |= 1u << i;
             }
         }
-        s_inv[idx] = inv;
         s_a[idx] = (bits ^ km_first) | inv;
     }
     __syncthreads();
@@ -166,7 +177,10 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
 #pragma unroll
         for (int i = 0; i < WORDS_PER_THREAD; i++) {
             const int idx = v0 + tid + 256 * i;
-            if (idx < v1) cur[idx] = last ? (acc[i] ^ flip) : ((acc[i] ^ flip) | s_inv[idx]);
+            if (idx < v1) {
+                const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LW;
+                cur[idx] = last ? (acc[i] ^ flip) : ((acc[i] ^ flip) | s_rinv[r] | s_cinv[k]);
+            }
         }
         __syncthreads();
     }
