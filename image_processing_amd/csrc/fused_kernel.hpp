@@ -188,6 +188,16 @@ struct RowBGR {  // one raw row of this lane's 4 pixels as packed 16-bit fields 
     uint32_t c2[2];   // (c2 of px0, px1), (px2, px3)
 };
 
+// The 3x3 pre-blur runs on 16 * value, so that after its two 1-2-1 passes (x16) the blurred value is byte 1 / byte 3
+// of a field and comes out, times 4, with one SDWA shift (fields stay below 2^16: 16 * (255 * 16 + 8) = 65408).
+__device__ __forceinline__ void scale16(RowBGR &o)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) o.c01[k] <<= 4;
+    o.c2[0] <<= 4;
+    o.c2[1] <<= 4;
+}
+
 __device__ __forceinline__ void unpack_row(const uint32_t (&w)[3], RowBGR &o)
 {
     // v_perm_b32 byte selectors: 0-3 = bytes of the second operand, 4-7 = bytes of the first, 0x0C = 0x00
@@ -197,20 +207,21 @@ __device__ __forceinline__ void unpack_row(const uint32_t (&w)[3], RowBGR &o)
     o.c01[3] = __builtin_amdgcn_perm(w[2], w[2], 0x0C020C01u);
     o.c2[0] = __builtin_amdgcn_perm(w[1], w[0], 0x0C050C02u);
     o.c2[1] = __builtin_amdgcn_perm(w[2], w[2], 0x0C030C00u);
+    scale16(o);
 }
 
-// GaussianBlur 3x3 (objectPolygonPath.cpp:182) on the raw channels, then HSV.  Fields hold 16*value + 8 after the two
-// 1-2-1 passes (the +8 is the folded rounding: +2 per field in the vertical pass times the horizontal weight 4), so the
-// channel value times 4 that hsv_px wants is (field >> 2) & 0x3FC.
+// GaussianBlur 3x3 (objectPolygonPath.cpp:182) on the raw channels, then HSV.  Fields hold 16 * (16*value + 8) after the two
+// 1-2-1 passes (inputs are pre-scaled by 16, see scale16; the folded rounding is +32 per field in the vertical pass), so the
+// channel value that hsv_px wants (times 4) is byte 1 of a field, shifted: byte_x4<1> / byte_x4<3>.
 template <bool RGB>
 __device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &r1, const RowBGR &r2, int border_strip,
                                                 bool lb_halo, bool rb_halo, const char *tab, Row &o)
 {
     uint32_t v[4], u[2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = r0.c01[k] + r2.c01[k] + 0x00020002u + (r1.c01[k] << 1);
+    for (int k = 0; k < 4; k++) v[k] = r0.c01[k] + r2.c01[k] + 0x00200020u + (r1.c01[k] << 1);
 #pragma unroll
-    for (int k = 0; k < 2; k++) u[k] = r0.c2[k] + r2.c2[k] + 0x00020002u + (r1.c2[k] << 1);
+    for (int k = 0; k < 2; k++) u[k] = r0.c2[k] + r2.c2[k] + 0x00200020u + (r1.c2[k] << 1);
     if (border_strip) {  // BORDER_REFLECT_101 left/right: col -1 = col 1, col w = col w-2 (see the post-blur patch)
         const uint32_t a1 = from_right(v[1]), au = from_right(u[0]);  // lane+1's px1 / (R0,R1)
         const uint32_t b2 = from_left(v[2]), bu = from_left(u[1]);    // lane-1's px2 / (R2,R3)
@@ -232,8 +243,8 @@ __device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t f2 = h2[k >> 1];
-        const uint32_t c2 = (k & 1) ? ((f2 >> 18) & 0x3FCu) : ((f2 >> 2) & 0x3FCu);
-        hsv_px<RGB>((h01[k] >> 2) & 0x3FCu, (h01[k] >> 18) & 0x3FCu, c2, tab, o.hs[k], vv[k]);
+        const uint32_t c2 = (k & 1) ? byte_x4<3>(f2) : byte_x4<1>(f2);
+        hsv_px<RGB>(byte_x4<1>(h01[k]), byte_x4<3>(h01[k]), c2, tab, o.hs[k], vv[k]);
     }
     o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;
     o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
@@ -285,15 +296,26 @@ __device__ __forceinline__ void demosaic_row(const uint32_t (&w)[3], bool odd_ro
     }
 }
 
+// 16-bit field H of w, times 4, in one SDWA shift
+template <int H>
+__device__ __forceinline__ uint32_t word_x4(uint32_t w)
+{
+    uint32_t r;
+    const uint32_t two = 2u;
+    if (H == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(two), "v"(w));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
+
 __device__ __forceinline__ void hsv_row_pairs(const Pairs &p, const char *tab, Row &o)
 {
-    uint32_t vv[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int q = k & 1, sh = (k >> 1) * 16;
-        hsv_px<false>(((p.b[q] >> sh) & 0xFFFFu) << 2, ((p.g[q] >> sh) & 0xFFFFu) << 2, ((p.r[q] >> sh) & 0xFFFFu) << 2, tab,
-                      o.hs[k], vv[k]);
-    }
+    uint32_t vv[4];  // pixel k sits in pair k & 1, field k >> 1
+    hsv_px<false>(word_x4<0>(p.b[0]), word_x4<0>(p.g[0]), word_x4<0>(p.r[0]), tab, o.hs[0], vv[0]);
+    hsv_px<false>(word_x4<0>(p.b[1]), word_x4<0>(p.g[1]), word_x4<0>(p.r[1]), tab, o.hs[1], vv[1]);
+    hsv_px<false>(word_x4<1>(p.b[0]), word_x4<1>(p.g[0]), word_x4<1>(p.r[0]), tab, o.hs[2], vv[2]);
+    hsv_px<false>(word_x4<1>(p.b[1]), word_x4<1>(p.g[1]), word_x4<1>(p.r[1]), tab, o.hs[3], vv[3]);
     o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;
     o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
 }
@@ -306,6 +328,7 @@ __device__ __forceinline__ void pairs_to_row(const Pairs &p, RowBGR &o)
     o.c01[3] = __builtin_amdgcn_perm(p.g[1], p.b[1], 0x07060302u);
     o.c2[0] = __builtin_amdgcn_perm(p.r[1], p.r[0], 0x05040100u);
     o.c2[1] = __builtin_amdgcn_perm(p.r[1], p.r[0], 0x07060302u);
+    scale16(o);
 }
 
 // vertical 1-4-6-4-1 on packed fields, +8 per field (the folded rounding)
