@@ -120,8 +120,10 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
         const auto &B = plan.bounds;
         bool never = false;
         for (int c = 0; c < 3; c++) never |= B.lo[r][c] > B.hi[r][c];
-        auto lo16 = [&](int c) { return (uint32_t)B.lo[r][c] << sh; };
-        auto hi16 = [&](int c) { return ((uint32_t)B.hi[r][c] << sh) | (sh ? 0xFFu : 0u); };
+        // 8.8 fields of the blurred image: the kernel leaves OpenCV's rounding constant (+128) out of the blur, so the
+        // bounds move down by 128 instead: lo*256 <= x + 128 <= hi*256 + 255 (a negative lower bound is 0: x >= 0)
+        auto lo16 = [&](int c) { const int v = ((int)B.lo[r][c] << sh) - (sh ? 128 : 0); return (uint32_t)(v < 0 ? 0 : v); };
+        auto hi16 = [&](int c) { return (((uint32_t)B.hi[r][c] << sh) | (sh ? 0xFFu : 0u)) - (sh ? 128u : 0u); };
         if (never) {  // an empty channel interval empties the whole mask: make the V test unsatisfiable
             a.hs_lo[r] = 0;
             a.hs_hi[r] = 0xFFFFFFFFu;

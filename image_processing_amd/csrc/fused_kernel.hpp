@@ -192,10 +192,12 @@ struct RowBGR {  // one raw row of this lane's 4 pixels as packed 16-bit fields 
 // of a field and comes out, times 4, with one SDWA shift (fields stay below 2^16: 16 * (255 * 16 + 8) = 65408).
 __device__ __forceinline__ void scale16(RowBGR &o)
 {
+    // + 8 per field: the rounding of the 3x3 blur (8 * (1+2+1) * (1+2+1) = 128 = half an output unit), folded into the
+    // same v_lshl_add_u32 that scales
 #pragma unroll
-    for (int k = 0; k < 4; k++) o.c01[k] <<= 4;
-    o.c2[0] <<= 4;
-    o.c2[1] <<= 4;
+    for (int k = 0; k < 4; k++) o.c01[k] = (o.c01[k] << 4) + 0x00080008u;
+    o.c2[0] = (o.c2[0] << 4) + 0x00080008u;
+    o.c2[1] = (o.c2[1] << 4) + 0x00080008u;
 }
 
 __device__ __forceinline__ void unpack_row(const uint32_t (&w)[3], RowBGR &o)
@@ -211,7 +213,7 @@ __device__ __forceinline__ void unpack_row(const uint32_t (&w)[3], RowBGR &o)
 }
 
 // GaussianBlur 3x3 (objectPolygonPath.cpp:182) on the raw channels, then HSV.  Fields hold 16 * (16*value + 8) after the two
-// 1-2-1 passes (inputs are pre-scaled by 16, see scale16; the folded rounding is +32 per field in the vertical pass), so the
+// 1-2-1 passes (inputs are 16 * byte + 8, see scale16: scale and folded rounding), so the
 // channel value that hsv_px wants (times 4) is byte 1 of a field, shifted: byte_x4<1> / byte_x4<3>.
 template <bool RGB>
 __device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &r1, const RowBGR &r2, int border_strip,
@@ -219,9 +221,9 @@ __device__ __forceinline__ void preblur_hsv_row(const RowBGR &r0, const RowBGR &
 {
     uint32_t v[4], u[2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = r0.c01[k] + r2.c01[k] + 0x00200020u + (r1.c01[k] << 1);
+    for (int k = 0; k < 4; k++) v[k] = r0.c01[k] + r2.c01[k] + (r1.c01[k] << 1);
 #pragma unroll
-    for (int k = 0; k < 2; k++) u[k] = r0.c2[k] + r2.c2[k] + 0x00200020u + (r1.c2[k] << 1);
+    for (int k = 0; k < 2; k++) u[k] = r0.c2[k] + r2.c2[k] + (r1.c2[k] << 1);
     if (border_strip) {  // BORDER_REFLECT_101 left/right: col -1 = col 1, col w = col w-2 (see the post-blur patch)
         const uint32_t a1 = from_right(v[1]), au = from_right(u[0]);  // lane+1's px1 / (R0,R1)
         const uint32_t b2 = from_left(v[2]), bu = from_left(u[1]);    // lane-1's px2 / (R2,R3)
@@ -331,10 +333,11 @@ __device__ __forceinline__ void pairs_to_row(const Pairs &p, RowBGR &o)
     scale16(o);
 }
 
-// vertical 1-4-6-4-1 on packed fields, +8 per field (the folded rounding)
+// vertical 1-4-6-4-1 on packed fields.  OpenCV's rounding constant (+128 on the 8.8 result) is NOT added here: the
+// host subtracts it from the inRange bounds instead (launch_fused), which saves a three-input add per register.
 __device__ __forceinline__ uint32_t vert5(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4)
 {
-    uint32_t t = a0 + a4 + 0x00080008u;
+    uint32_t t = a0 + a4;
     t += (a1 + a3) << 2;
     return mad_u24(a2, 6u, t);  // a2 <= 0x00FF00FF < 2^24
 }
