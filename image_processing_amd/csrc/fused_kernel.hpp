@@ -16,8 +16,8 @@
 //    gets its +-2 px neighbours from the adjacent lanes with DPP wave shifts.
 //  * Pixels are kept as packed 16-bit fields (H|S<<16 per pixel, V pairs), so every Gaussian add /
 //    shift-add processes two values per VALU op; sums stay < 2^16 per field (max 255*256+128).
-//    The single rounding (x+128)>>8 is folded in as +8 in the vertical pass and never materialised:
-//    inRange compares the 8.8 field against (lo<<8, hi<<8|255).
+//    The single rounding (x+128)>>8 is never materialised: inRange compares the raw 8.8 sum against
+//    (lo<<8 - 128, (hi<<8|255) - 128), the rounding constant having moved into the bounds on the host.
 //  * inRange results are shifted into a per-lane 4-col x 8-row bit tile; 3x3 erode/dilate are a dozen
 //    bit operations on that tile (horizontal neighbours again by DPP), 32 pixels per op.
 //  * Moments are popcounts of the final tile; mask bytes are expanded from the tile rows and stored
