@@ -177,15 +177,19 @@ __global__ __launch_bounds__(256) void k_gaussian_strip(const u8 *__restrict__ s
 #pragma unroll
         for (int q = 0; q < GS_LANE_BYTES; q++) {
             const int dc = 2 * ((q >> 2) - G::G0) + (q & 1), hc = (q >> 1) & 1;
-            uint32_t a = gs_mulw(tapc, win[dc], hc);
+            // all pair sums first, then the multiply-add chain: an SDWA result consumed by the very next
+            // instruction costs a wait state
+            uint32_t sp[R > 0 ? R : 1];
 #pragma unroll
             for (int i = 1; i <= R; i++) {
                 const int rm = q - i * CN, rp = q + i * CN;
                 const int gm = gs_floor_shr2(rm), gp = gs_floor_shr2(rp);
                 const int qm = rm - 4 * gm, qp = rp - 4 * gp;
-                const uint32_t s = gs_addw(win[2 * (gm - G::G0) + (qm & 1)], qm >> 1, win[2 * (gp - G::G0) + (qp & 1)], qp >> 1);
-                a = gs_mad(taps.t[R - i], s, a);
+                sp[i - 1] = gs_addw(win[2 * (gm - G::G0) + (qm & 1)], qm >> 1, win[2 * (gp - G::G0) + (qp & 1)], qp >> 1);
             }
+            uint32_t a = gs_mulw(tapc, win[dc], hc);
+#pragma unroll
+            for (int i = 1; i <= R; i++) a = gs_mad(taps.t[R - i], sp[i - 1], a);
             acc[q] = a;
         }
         // byte 2 of every accumulator is the result
