@@ -86,3 +86,34 @@ def test_config5_stress_7680x4320():
         assert [res_a[r][k] for k in KEYS] == [res_b[r][k] for k in KEYS] == mask_sums(masks_a[r])
         hit += res_a[r]["m00"] > 0
     assert hit >= 4
+
+
+@pytest.mark.parametrize("case", [("bgr", 1920, 1200), ("bgr", 1918, 1203), ("bayer", 2448, 2048)])
+def test_full_size_noise_vs_oracle(oracle, case):
+    """Full-size frames of structured noise (every pixel carries information, so every strip / segment boundary of the
+    chain kernel shows up if it is wrong) for the three chains, two ranges, against the oracle: masks bit for bit,
+    moments exact."""
+    enc, w, h = case
+    rng = np.random.default_rng(w * 7 + h)
+    shape = (h, w) if enc == "bayer" else (h, w, 3)
+    frame = rng.integers(0, 256, shape, dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    blob = (np.sin(xx / 37.0) * np.cos(yy / 29.0)) > 0.2
+    frame = np.where(blob if enc == "bayer" else blob[:, :, None], frame, frame // 3).astype(np.uint8)
+    ranges = [((0, 30, 60), (110, 256, 256)), ((90, 0, 0), (180, 140, 90))]
+    presets = {"pose_estimate": dict(pre_blur_k=0, post_blur_k=0, morph=[]),
+               "baseline": dict(pre_blur_k=0, post_blur_k=5, morph=ip.MORPH_BASELINE),
+               "polygon_path": dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH)}
+    with ip.ImgProc(w, h, n_slots=1) as g:
+        for name, kw in presets.items():
+            g.set_pipeline(encoding=L.ENC_BAYER_RGGB8 if enc == "bayer" else L.ENC_BGR8, second_order=True, **kw)
+            g.set_ranges(ranges)
+            assert "stage kernels" not in g.plan
+            res = g.process(frame)
+            exp = oracle.chain(frame, encoding=2 if enc == "bayer" else 0, pre_blur_k=kw["pre_blur_k"],
+                               post_blur_k=kw["post_blur_k"], morph=morph_tuples(kw["morph"]), ranges=ranges, stages=False)
+            for r in range(2):
+                assert (g.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all(), (case, name, r)
+                got = [res[r][k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")]
+                assert got == [int(v) for v in exp["moments"][r]], (case, name, r)
+            assert sum(int(m[0]) for m in exp["moments"]) > 0 or name == "polygon_path"
