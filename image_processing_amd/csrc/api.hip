@@ -114,7 +114,7 @@ int gaussian_taps(int k, int *taps)
     default: break;
     }
     const long double sigma = ((k - 1) * 0.5L - 1.0L) * 0.3L + 0.8L;
-    std::vector<long double> g(k);
+    long double g[IMGPROC_MAX_KSIZE];
     long double tot = 0;
     for (int i = 0; i < k; i++) {
         long double x = i - (k - 1) * 0.5L;
@@ -142,12 +142,12 @@ int make_element(const imgproc_morph &m, const u8 *custom, ipk::Element &e)
     e.ax = m.anchor_x < 0 ? m.kw / 2 : m.anchor_x;
     e.ay = m.anchor_y < 0 ? m.kh / 2 : m.anchor_y;
     if (e.ax >= m.kw || e.ay >= m.kh) return IMGPROC_EINVAL;
-    std::vector<u8> bits((size_t)m.kw * m.kh);
+    u8 bits[IMGPROC_MAX_KSIZE * IMGPROC_MAX_KSIZE];
     if (m.shape == IMGPROC_CUSTOM) {
         if (!custom) return IMGPROC_EINVAL;
-        memcpy(bits.data(), custom, bits.size());
+        memcpy(bits, custom, (size_t)m.kw * m.kh);
     } else {
-        int rc = imgproc_structuring_element(m.shape, m.kw, m.kh, bits.data());
+        int rc = imgproc_structuring_element(m.shape, m.kw, m.kh, bits);
         if (rc) return rc;
     }
     bool all = true;
@@ -354,6 +354,9 @@ IMGPROC_API int imgproc_device_count(int *count)
     return IMGPROC_OK;
 }
 
+// No C++ exception crosses the ABI: the two entry points that grow std::vectors (the slots, the plan) catch bad_alloc.
+static int set_pipeline_impl(imgproc_ctx *c, const imgproc_pipeline *pp);
+
 IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
 {
     if (!out || !cfg) return IMGPROC_EINVAL;
@@ -401,7 +404,12 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
         }
         return 0;
     };
-    int rc = build();
+    int rc;
+    try {
+        rc = build();
+    } catch (...) {
+        rc = IMGPROC_ENOMEM;
+    }
     if (rc) {
         imgproc_destroy(c);
         return rc;
@@ -456,6 +464,15 @@ static void replan_fused(imgproc_ctx *c)
 }
 
 IMGPROC_API int imgproc_set_pipeline(imgproc_ctx *c, const imgproc_pipeline *pp)
+{
+    try {
+        return set_pipeline_impl(c, pp);
+    } catch (...) {
+        return fail(c, IMGPROC_ENOMEM, "set_pipeline: out of host memory");
+    }
+}
+
+static int set_pipeline_impl(imgproc_ctx *c, const imgproc_pipeline *pp)
 {
     if (!c || !pp) return IMGPROC_EINVAL;
     if (pp->encoding < 0 || pp->encoding > IMGPROC_ENC_BAYER_RGGB8) return fail(c, IMGPROC_EINVAL, "encoding %d", pp->encoding);
