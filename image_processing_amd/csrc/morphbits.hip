@@ -9,15 +9,18 @@
 // HBM traffic: 1 B/px read (+ halo from L2) and 1 B/px written instead of 2 B/px per op.
 #include "morphbits.h"
 
+#include <type_traits>
+
 namespace ipm {
 
 using ipk::u8;
 
 constexpr int TWW = 16;  // interior tile width in 32-px words (512 px)
 constexpr int TH = 96;   // interior tile height
-constexpr int MAX_HALO_ROWS = 64;
+constexpr int MAX_HALO_ROWS = 56;
 constexpr int MAX_HALO_WORDS = 2;  // per side
 constexpr int LW_MAX = TWW + 2 * MAX_HALO_WORDS;
+constexpr int LS_MAX = LW_MAX + 1;  // row stride in LDS: the data words + one pad word that stays all-ones
 constexpr int LH_MAX = TH + MAX_HALO_ROWS;
 
 struct Args {
@@ -32,54 +35,21 @@ struct Args {
     int second_order;
 };
 
-// AND of the bits x+lo .. x+hi (|lo|,|hi| <= 32) for the 32 positions x of word `c`; p / n are the previous / next words.
-__device__ __forceinline__ uint32_t window_and(uint32_t p, uint32_t c, uint32_t n, int lo, int hi)
-{
-    // 96-bit row segment, bit i of word k = position 32k+i; doubling: f_len(x) = AND of len bits starting at x
-    uint32_t a0 = p, a1 = c, a2 = n;
-    const int len = hi - lo + 1;
-    int have = 1;
-    auto shr96 = [](uint32_t &x0, uint32_t &x1, uint32_t &x2, int s) {  // positions move down by s (value at x+s -> x)
-        while (s >= 32) {
-            x0 = x1; x1 = x2; x2 = 0xFFFFFFFFu;
-            s -= 32;
-        }
-        if (s) {
-            x0 = (x0 >> s) | (x1 << (32 - s));
-            x1 = (x1 >> s) | (x2 << (32 - s));
-            x2 = (x2 >> s) | (0xFFFFFFFFu << (32 - s));
-        }
-    };
-    while (have * 2 <= len) {
-        uint32_t b0 = a0, b1 = a1, b2 = a2;
-        shr96(b0, b1, b2, have);
-        a0 &= b0; a1 &= b1; a2 &= b2;
-        have *= 2;
-    }
-    if (have < len) {
-        uint32_t b0 = a0, b1 = a1, b2 = a2;
-        shr96(b0, b1, b2, len - have);
-        a0 &= b0; a1 &= b1; a2 &= b2;
-    }
-    // now a(x) = AND of bits x .. x+len-1; we need it at x+lo: shift by 32+lo positions (lo in [-32, 32])
-    const int s = 32 + lo;  // 0..64
-    if (s >= 64) return a2;  // s == 64 (lo == 32)
-    if (s >= 32) {
-        const int t = s - 32;
-        return t ? ((a1 >> t) | (a2 << (32 - t))) : a1;
-    }
-    return s ? ((a0 >> s) | (a1 << (32 - s))) : a0;
-}
-
-constexpr int N_WORDS_MAX = LH_MAX * LW_MAX;
+constexpr int N_WORDS_MAX = LH_MAX * LS_MAX;
 constexpr int WORDS_PER_THREAD = (N_WORDS_MAX + 255) / 256;
+static_assert(WORDS_PER_THREAD == 13, "the vertical pass is instantiated for 1..13 words per thread");
+constexpr int CH = 4;  // words a thread carries through one horizontal window pass at a time
 
-__global__ __launch_bounds__(256) void k_bitmorph(const Args a)
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, int s) { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s); }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_bitmorph(const Args a)
 {
-    __shared__ uint32_t s_a[N_WORDS_MAX];
-    __shared__ uint32_t s_b[N_WORDS_MAX];
+    // Two bit planes of the tile (current / horizontal-pass output), rows of LS = LW + 1 words: the extra word of every
+    // row (and the word before the first row) is all-ones, the neutral value of the erode domain everything is stored
+    // in, so the horizontal pass reads its left / right neighbour words without looking at the column index.
+    __shared__ uint32_t s_buf[2 * N_WORDS_MAX + 2];
     // bits outside the image (neutral for every op: OpenCV's morphologyDefaultBorderValue) = row part | column part
-    __shared__ uint32_t s_rinv[LH_MAX], s_cinv[LW_MAX];
+    __shared__ uint32_t s_rinv[LH_MAX], s_cinv[LS_MAX];
     __shared__ unsigned long long s_red[4][6];
 
     const int tid = threadIdx.x;
@@ -88,19 +58,21 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
     const int ty = t % a.tiles_y; t /= a.tiles_y;
     const int plane = t;
     const int w = a.w, h = a.h;
-    const int LW = TWW + a.hwl + a.hwr, LH = TH + a.ht + a.hb;
-    const uint32_t rcp = (65536u + LW - 1) / LW;  // idx / LW == (idx * rcp) >> 16 for idx < 3277 (LW <= 20)
+    const int LW = TWW + a.hwl + a.hwr, LS = LW + 1, LH = TH + a.ht + a.hb;
+    const uint32_t rcp = (65536u + LS - 1) / LS;  // idx / LS == (idx * rcp) >> 16 for idx < 3400 (LS <= 21)
     const int x_org = (tx * TWW - a.hwl) * 32;  // pixel x of tile word 0
     const int y_org = ty * TH - a.ht;
     const u8 *src = a.thresh + (size_t)plane * w * h;
     const bool vec = true;  // dword accesses may be unaligned (w % 4 != 0): fine for gfx950 global memory (scripts/ubench/unaligned.hip)
     auto mask_of = [](int kind) { return kind ? 0xFFFFFFFFu : 0u; };  // dilate(X) = ~erode(~X)
+    uint32_t *const cur = s_buf + 1, *const alt = s_buf + N_WORDS_MAX + 2;
 
+    if (tid == 0) cur[-1] = 0xFFFFFFFFu;
     if (tid < LH) s_rinv[tid] = (y_org + tid >= 0 && y_org + tid < h) ? 0u : 0xFFFFFFFFu;
-    if (tid < LW) {
+    if (tid < LS) {
         const int x0 = x_org + tid * 32;
         uint32_t inv = 0xFFFFFFFFu;
-        if (x0 < w && x0 + 32 > 0) {
+        if (tid < LW && x0 < w && x0 + 32 > 0) {
             inv = 0;
             if (x0 < 0) inv |= (1u << (-x0)) - 1u;             // x0 in (-32, 0)
             if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);  // partially beyond the right edge
@@ -109,9 +81,9 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
     }
     // ---- pack: one 32-px word per thread-iteration, stored in the first group's erode domain ----
     const uint32_t km_first = mask_of(a.groups[0].kind);
-    for (int idx = tid; idx < LH * LW; idx += 256) {
-        const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LW;
-        const int y = y_org + r, x0 = x_org + k * 32;
+    for (int idx = tid; idx < LH * LS; idx += 256) {
+        const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
+        const int y = y_org + r, x0 = k == LW ? w : x_org + k * 32;  // the pad word: "outside" -> all-ones
         uint32_t bits = 0, inv = 0xFFFFFFFFu;
         if (y >= 0 && y < h && x0 < w && x0 + 32 > 0) {
             inv = 0;
@@ -120,56 +92,124 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
             const u8 *row = src + (size_t)y * w;
             if (vec && x0 >= 0 && x0 + 32 <= w) {
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x0);
+                // 0/255 bytes -> bits: two dwords (8 px) per byte of the word, one 4x8-bit dot product each
 #pragma unroll
-                for (int q = 0; q < 8; q++) bits |= (((p[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t hi4 = __builtin_amdgcn_udot4(p[2 * q + 1] & 0x01010101u, 0x80402010u, 0u, false);
+                    bits |= __builtin_amdgcn_udot4(p[2 * q] & 0x01010101u, 0x08040201u, hi4, false) << (8 * q);
+                }
             } else {
                 for (int i = 0; i < 32; i++)
                     if (x0 + i >= 0 && x0 + i < w && row[x0 + i]) bits |= 1u << i;
             }
         }
-        s_a[idx] = (bits ^ km_first) | inv;
+        cur[idx] = (bits ^ km_first) | inv;
     }
     __syncthreads();
 
     // Every group: for each distinct span of its element, a horizontal window AND of the whole tile (cur -> alt), then
     // the AND over the rows that use that span, accumulated in registers; the result goes back into cur already in the
     // NEXT group's erode domain.  Rows a group can no longer produce correctly (reach of the groups so far) are skipped.
-    uint32_t *const cur = s_a, *const alt = s_b;
+    // All loop control is uniform (scalar) and amortised over the CH / WORDS_PER_THREAD words a thread holds.
     for (int gi = 0; gi < a.n_groups; gi++) {
         const Group &g = a.groups[gi];
         const bool last = gi + 1 == a.n_groups;
         const uint32_t flip = mask_of(g.kind) ^ (last ? 0u : mask_of(a.groups[gi + 1].kind));
-        const int h0 = g.t_in * LW, h1 = (LH - g.b_in) * LW;
-        const int v0 = g.t_out * LW, v1 = (LH - g.b_out) * LW;
+        const int h0 = g.t_in * LS, h1 = (LH - g.b_in) * LS;
+        const int v0 = g.t_out * LS, v1 = (LH - g.b_out) * LS;
         uint32_t acc[WORDS_PER_THREAD];
 #pragma unroll
         for (int i = 0; i < WORDS_PER_THREAD; i++) acc[i] = 0xFFFFFFFFu;
+        // this thread's output words are v0 + tid + 256 i, i < n_it; the last one is clamped into the valid range (its
+        // surplus lanes compute but never store)
+        const int n_it = (v1 - v0 + 255) >> 8;
+        const int vfirst = v0 + tid, vlast = min(v0 + tid + 256 * (n_it - 1), v1 - 1);
         for (int si = 0; si < g.n_spans; si++) {
             const Span sp = g.spans[si];
             const uint32_t *hsrc = cur;
             if (sp.lx != 0 || sp.hx != 0) {
-                for (int idx = h0 + tid; idx < h1; idx += 256) {
-                    const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LW;
-                    const uint32_t p = k > 0 ? cur[idx - 1] : 0xFFFFFFFFu;
-                    const uint32_t n = k < LW - 1 ? cur[idx + 1] : 0xFFFFFFFFu;
-                    alt[idx] = window_and(p, cur[idx], n, sp.lx, sp.hx);
-                }
+                // window AND of the bits x+lx .. x+hx on the 96-bit string (previous, this, next word): doubling
+                // (f_2n(x) = f_n(x) & f_n(x+n)), then the string is read at offset 32 + lx
+                const int len = sp.hx - sp.lx + 1, ex = 32 + sp.lx;  // len 1..65, ex 0..64
+                auto hpass = [&](auto cn, int base) {  // C words per thread starting at base + tid
+                    constexpr int C = decltype(cn)::value;
+                    uint32_t a0[C], a1[C], a2[C];
+#pragma unroll
+                    for (int j = 0; j < C; j++) {
+                        const int idx = min(base + tid + 256 * j, h1 - 1);
+                        a0[j] = cur[idx - 1];
+                        a1[j] = cur[idx];
+                        a2[j] = cur[idx + 1];
+                    }
+                    auto step = [&](int s) {  // a(x) &= a(x + s), 1 <= s <= 32; ones come in from beyond the string
+                        if (s == 32) {
+#pragma unroll
+                            for (int j = 0; j < C; j++) a0[j] &= a1[j], a1[j] &= a2[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < C; j++) {
+                                a0[j] &= funnel(a1[j], a0[j], s);
+                                a1[j] &= funnel(a2[j], a1[j], s);
+                                a2[j] &= funnel(0xFFFFFFFFu, a2[j], s);
+                            }
+                        }
+                    };
+                    int have = 1;
+#pragma unroll 1
+                    while (have * 2 <= len) {
+                        step(have);
+                        have *= 2;
+                    }
+                    if (have < len) step(len - have);
+#pragma unroll
+                    for (int j = 0; j < C; j++) {
+                        const int idx = base + tid + 256 * j;
+                        const uint32_t res = ex >= 64 ? a2[j] : ex >= 32 ? funnel(a2[j], a1[j], ex - 32) : funnel(a1[j], a0[j], ex);
+                        if (idx < h1) alt[idx] = res;
+                    }
+                };
+                int base = h0;
+#pragma unroll 1
+                for (; h1 - base > 2 * 256; base += 256 * CH) hpass(std::integral_constant<int, CH>(), base);
+                if (h1 - base > 256)
+                    hpass(std::integral_constant<int, 2>(), base);
+                else if (h1 - base > 0)
+                    hpass(std::integral_constant<int, 1>(), base);
                 __syncthreads();
                 hsrc = alt;
             }
+            // AND over the rows of the span, N = n_it words per thread: one address per row + immediate offsets
+            auto vpass = [&](auto nn) {
+                constexpr int N = decltype(nn)::value;
+                auto and_row = [&](int dy) {
+                    const uint32_t *rowp = hsrc + dy * LS;
+                    const uint32_t *pf = rowp + vfirst;
 #pragma unroll
-            for (int i = 0; i < WORDS_PER_THREAD; i++) {
-                const int idx = v0 + tid + 256 * i;
-                if (idx < v1) {
-                    uint32_t x = acc[i];
-                    const uint32_t *col = hsrc + idx + sp.dy_lo * LW;
-                    if (sp.rows == 0) {
-                        for (int d = sp.dy_hi - sp.dy_lo; d >= 0; d--) x &= col[d * LW];
-                    } else {
-                        for (uint32_t m = sp.rows; m; m &= m - 1) x &= col[(__ffs(m) - 1) * LW];
-                    }
-                    acc[i] = x;
+                    for (int i = 0; i < N - 1; i++) acc[i] &= pf[256 * i];
+                    acc[N - 1] &= rowp[vlast];
+                };
+                if (sp.rows == 0) {
+#pragma unroll 1
+                    for (int dy = sp.dy_lo; dy <= sp.dy_hi; dy++) and_row(dy);
+                } else {
+#pragma unroll 1
+                    for (uint32_t m = sp.rows; m; m &= m - 1) and_row(sp.dy_lo + __ffs(m) - 1);
                 }
+            };
+            switch (n_it) {
+            case 1: vpass(std::integral_constant<int, 1>()); break;
+            case 2: vpass(std::integral_constant<int, 2>()); break;
+            case 3: vpass(std::integral_constant<int, 3>()); break;
+            case 4: vpass(std::integral_constant<int, 4>()); break;
+            case 5: vpass(std::integral_constant<int, 5>()); break;
+            case 6: vpass(std::integral_constant<int, 6>()); break;
+            case 7: vpass(std::integral_constant<int, 7>()); break;
+            case 8: vpass(std::integral_constant<int, 8>()); break;
+            case 9: vpass(std::integral_constant<int, 9>()); break;
+            case 10: vpass(std::integral_constant<int, 10>()); break;
+            case 11: vpass(std::integral_constant<int, 11>()); break;
+            case 12: vpass(std::integral_constant<int, 12>()); break;
+            default: vpass(std::integral_constant<int, 13>()); break;
             }
             if (hsrc == alt && si + 1 < g.n_spans) __syncthreads();  // alt is rewritten by the next span
         }
@@ -178,7 +218,7 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
         for (int i = 0; i < WORDS_PER_THREAD; i++) {
             const int idx = v0 + tid + 256 * i;
             if (idx < v1) {
-                const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LW;
+                const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
                 cur[idx] = last ? (acc[i] ^ flip) : ((acc[i] ^ flip) | s_rinv[r] | s_cinv[k]);
             }
         }
@@ -192,7 +232,7 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
         const int r = idx / TWW, k = idx - r * TWW;
         const int y = ty * TH + r, x0 = (tx * TWW + k) * 32;
         if (y >= h || x0 >= w) continue;
-        uint32_t bits = cur[(r + a.ht) * LW + (k + a.hwl)];
+        uint32_t bits = cur[(r + a.ht) * LS + (k + a.hwl)];
         if (x0 + 32 > w) bits &= (1u << (w - x0)) - 1u;
         if (dst) {
             u8 *o = dst + (size_t)y * w + x0;
@@ -201,7 +241,7 @@ __global__ __launch_bounds__(256) void k_bitmorph(const Args a)
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const uint32_t nib = (bits >> (4 * q)) & 15u;
-                    o32[q] = __builtin_amdgcn_perm(0u, 0x0000FF00u, (nib * 0x00204081u) & 0x01010101u);
+                    o32[q] = __builtin_amdgcn_perm(0u, 0x0000FF00u, __umul24(nib, 0x00204081u) & 0x01010101u);
                 }
             } else {
                 for (int i = 0; i < 32 && x0 + i < w; i++) o[i] = ((bits >> i) & 1u) ? 255 : 0;
