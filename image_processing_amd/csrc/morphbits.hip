@@ -15,8 +15,9 @@ namespace ipm {
 
 using ipk::u8;
 
-constexpr int TWW = 16;  // interior tile width in 32-px words (512 px)
-constexpr int TH = 96;   // interior tile height
+constexpr int TWW = 16;  // largest interior tile width in 32-px words (512 px)
+constexpr int TH = 96;   // largest interior tile height
+// the launch divides the image into equal tiles no larger than that (1920x1200: 4 x 13 tiles of 15 words x 93 rows)
 constexpr int MAX_HALO_ROWS = 56;
 constexpr int MAX_HALO_WORDS = 2;  // per side
 constexpr int LW_MAX = TWW + 2 * MAX_HALO_WORDS;
@@ -32,6 +33,7 @@ struct Args {
     int w, h, planes;
     int hwl, hwr, ht, hb;  // halo: words left/right, rows top/bottom
     int tiles_x, tiles_y;
+    int tww, th;  // interior tile size: words, rows
     int second_order;
 };
 
@@ -58,10 +60,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int ty = t % a.tiles_y; t /= a.tiles_y;
     const int plane = t;
     const int w = a.w, h = a.h;
-    const int LW = TWW + a.hwl + a.hwr, LS = LW + 1, LH = TH + a.ht + a.hb;
+    const int tww = a.tww, th = a.th;
+    const int LW = tww + a.hwl + a.hwr, LS = LW + 1, LH = th + a.ht + a.hb;
     const uint32_t rcp = (65536u + LS - 1) / LS;  // idx / LS == (idx * rcp) >> 16 for idx < 3400 (LS <= 21)
-    const int x_org = (tx * TWW - a.hwl) * 32;  // pixel x of tile word 0
-    const int y_org = ty * TH - a.ht;
+    const int x_org = (tx * tww - a.hwl) * 32;  // pixel x of tile word 0
+    const int y_org = ty * th - a.ht;
     const u8 *src = a.thresh + (size_t)plane * w * h;
     const bool vec = true;  // dword accesses may be unaligned (w % 4 != 0): fine for gfx950 global memory (scripts/ubench/unaligned.hip)
     auto mask_of = [](int kind) { return kind ? 0xFFFFFFFFu : 0u; };  // dilate(X) = ~erode(~X)
@@ -228,9 +231,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // ---- interior: bytes out + moments ----
     unsigned long long m[6] = {0, 0, 0, 0, 0, 0};
     u8 *dst = a.masks ? a.masks + (size_t)plane * w * h : nullptr;
-    for (int idx = tid; idx < TH * TWW; idx += 256) {
-        const int r = idx / TWW, k = idx - r * TWW;
-        const int y = ty * TH + r, x0 = (tx * TWW + k) * 32;
+    const uint32_t rcp_i = (65536u + tww - 1) / tww;  // idx / tww for idx < TH * TWW
+    for (int idx = tid; idx < th * tww; idx += 256) {
+        const int r = (int)(((uint32_t)idx * rcp_i) >> 16), k = idx - r * tww;
+        const int y = ty * th + r, x0 = (tx * tww + k) * 32;
         if (y >= h || x0 >= w) continue;
         uint32_t bits = cur[(r + a.ht) * LS + (k + a.hwl)];
         if (x0 + 32 > w) bits &= (1u << (w - x0)) - 1u;
@@ -390,8 +394,11 @@ hipError_t launch_bitmorph(const Plan &plan, const Group *d_groups, const u8 *d_
     a.n_groups = (int)plan.groups.size();
     a.w = w; a.h = h; a.planes = planes;
     a.hwl = plan.hwl; a.hwr = plan.hwr; a.ht = plan.ht; a.hb = plan.hb;
-    a.tiles_x = (w + TWW * 32 - 1) / (TWW * 32);
+    const int words = (w + 31) / 32;
+    a.tiles_x = (words + TWW - 1) / TWW;
     a.tiles_y = (h + TH - 1) / TH;
+    a.tww = (words + a.tiles_x - 1) / a.tiles_x;  // equal tiles: no mostly-empty last tile column / row
+    a.th = (h + a.tiles_y - 1) / a.tiles_y;
     a.second_order = second_order;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * planes;
     if (blocks > 0x7FFFFFFFLL) return hipErrorInvalidValue;
