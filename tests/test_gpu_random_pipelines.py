@@ -84,3 +84,42 @@ def test_random_pipeline(gpu, oracle, seed):
             assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp_masks[r]).all(), tag
             n = 6 if c["second"] else 3
             assert [res[r][k] for k in KEYS[:n]] == [int(v) for v in exp_moms[r][:n]], tag
+
+
+WIDE_CASES = {
+    # merged RECT windows up to -32..+32 (65 bits: the doubling takes its 32-bit step), no vertical reach
+    "rect_pm32": [(L.ERODE, L.RECT, 17, 1)] * 4,
+    "rect_pm30_dilate": [(L.DILATE, L.RECT, 21, 1)] * 3 + [(L.ERODE, L.RECT, 1, 25)],
+    # one-sided windows: anchor at the element's first / last column
+    "anchor_left": [(L.ERODE, L.RECT, 31, 3, (0, 1)), (L.DILATE, L.RECT, 31, 3, (30, 1))],
+    # tall reach: 2 x 27 rows (52 of the 56 halo rows), tiles_y > 1
+    "tall": [(L.DILATE, L.RECT, 3, 27), (L.ERODE, L.RECT, 3, 27)],
+    "ellipses": [(L.ERODE, L.ELLIPSE, 31, 15), (L.DILATE, L.ELLIPSE, 15, 31)],
+    "polygon_path": None,
+}
+
+
+@pytest.mark.parametrize("name", list(WIDE_CASES))
+@pytest.mark.parametrize("shape", [(300, 700), (97, 1283), (410, 64)])
+def test_bitplane_wide_windows(oracle, name, shape):
+    """The bit-plane kernel at its limits (window width, reach, partial tiles) against the oracle's erode / dilate."""
+    h, w = shape
+    rng = np.random.default_rng(h * 7 + w + len(name))
+    yy, xx = np.mgrid[0:h, 0:w]
+    blob = (np.sin(xx / 23.0) * np.cos(yy / 17.0) > -0.2) ^ (rng.random((h, w)) < 0.02)
+    frame = np.where(blob[:, :, None], np.array([200, 60, 40], np.uint8), np.array([10, 10, 10], np.uint8)).astype(np.uint8)
+    ops = ip.MORPH_POLYGON_PATH if WIDE_CASES[name] is None else [
+        ip.MorphOp(o[0], o[1], o[2], o[3], o[4] if len(o) > 4 else (-1, -1), None) for o in WIDE_CASES[name]]
+    ranges = [((100, 100, 100), (130, 256, 256))]
+    thresh = oracle.chain(frame, ranges=ranges, stages=True)["thresh"][0]
+    assert 0.2 < (thresh != 0).mean() < 0.95
+    exp = thresh
+    for op in ops:
+        exp = oracle.morph(exp, op.kind, oracle.structuring_element(op.shape, op.kw, op.kh), op.anchor)
+    with ip.ImgProc(w, h, n_slots=1, max_batch=1) as g:
+        g.set_pipeline(morph=ops, second_order=True)
+        g.set_ranges(ranges)
+        assert "bit-plane" in g.plan, g.plan
+        res = g.process(frame)
+        assert (g.fetch_stage(0, L.STAGE_MASK, 0) == exp).all(), (name, shape, g.plan)
+        assert [res[0][k] for k in KEYS] == [int(v) for v in oracle.moments(exp)]
