@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     // bits outside the image (neutral for every op: OpenCV's morphologyDefaultBorderValue) = row part | column part
     __shared__ uint32_t s_rinv[LH_MAX], s_cinv[LS_MAX];
     __shared__ unsigned long long s_red[4][6];
+    __shared__ uint32_t s_lut[16];  // nibble -> four 0/255 bytes
 
     const int tid = threadIdx.x;
     int t = blockIdx.x;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t *const cur = s_buf + 1, *const alt = s_buf + N_WORDS_MAX + 2;
 
     if (tid == 0) cur[-1] = 0xFFFFFFFFu;
+    if (tid < 16) s_lut[tid] = ((tid & 1) ? 0xFFu : 0u) | ((tid & 2) ? 0xFF00u : 0u) | ((tid & 4) ? 0xFF0000u : 0u) | ((tid & 8) ? 0xFF000000u : 0u);
     if (tid < LH) s_rinv[tid] = (y_org + tid >= 0 && y_org + tid < h) ? 0u : 0xFFFFFFFFu;
     if (tid < LS) {
         const int x0 = x_org + tid * 32;
@@ -84,29 +86,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     // ---- pack: one 32-px word per thread-iteration, stored in the first group's erode domain ----
     const uint32_t km_first = mask_of(a.groups[0].kind);
-    for (int idx = tid; idx < LH * LS; idx += 256) {
-        const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
-        const int y = y_org + r, x0 = k == LW ? w : x_org + k * 32;  // the pad word: "outside" -> all-ones
-        uint32_t bits = 0, inv = 0xFFFFFFFFu;
-        if (y >= 0 && y < h && x0 < w && x0 + 32 > 0) {
-            inv = 0;
-            if (x0 < 0) inv |= (1u << (-x0)) - 1u;
-            if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);
-            const u8 *row = src + (size_t)y * w;
-            if (vec && x0 >= 0 && x0 + 32 <= w) {
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x0);
-                // 0/255 bytes -> bits: two dwords (8 px) per byte of the word, one 4x8-bit dot product each
+    // PB words per thread at a time: all their global loads are issued before the first is used, so a thread waits for
+    // HBM two or three times per tile instead of once per word
+    constexpr int PB = 4;
+    for (int base = 0; base < LH * LS; base += 256 * PB) {
+        uint32_t v[PB][8];
+        int px0[PB], py[PB];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t hi4 = __builtin_amdgcn_udot4(p[2 * q + 1] & 0x01010101u, 0x80402010u, 0u, false);
-                    bits |= __builtin_amdgcn_udot4(p[2 * q] & 0x01010101u, 0x08040201u, hi4, false) << (8 * q);
-                }
-            } else {
-                for (int i = 0; i < 32; i++)
-                    if (x0 + i >= 0 && x0 + i < w && row[x0 + i]) bits |= 1u << i;
-            }
+        for (int j = 0; j < PB; j++) {
+            const int idx = base + tid + 256 * j;
+            const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
+            const int y = y_org + r, x0 = k == LW ? w : x_org + k * 32;  // the pad word: "outside" -> all-ones
+            px0[j] = x0;
+            py[j] = (idx < LH * LS && y >= 0 && y < h) ? y : -1;
+            const bool fast = vec && py[j] >= 0 && x0 >= 0 && x0 + 32 <= w;
+            // unconditional loads (words that take no fast path read the group list instead: always 32 readable bytes)
+            const uint32_t *p = fast ? reinterpret_cast<const uint32_t *>(src + (size_t)y * w + x0)
+                                     : reinterpret_cast<const uint32_t *>(a.groups);
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[j][q] = p[q];
         }
-        cur[idx] = (bits ^ km_first) | inv;
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int idx = base + tid + 256 * j;
+            const int y = py[j], x0 = px0[j];
+            uint32_t bits = 0, inv = 0xFFFFFFFFu;
+            if (y >= 0 && x0 < w && x0 + 32 > 0) {
+                inv = 0;
+                if (vec && x0 >= 0 && x0 + 32 <= w) {
+                    // 0/255 bytes -> bits: two dwords (8 px) per byte of the word, one 4x8-bit dot product each
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t hi4 = __builtin_amdgcn_udot4(v[j][2 * q + 1] & 0x01010101u, 0x80402010u, 0u, false);
+                        bits |= __builtin_amdgcn_udot4(v[j][2 * q] & 0x01010101u, 0x08040201u, hi4, false) << (8 * q);
+                    }
+                } else {  // a word that the image's left / right edge cuts
+                    if (x0 < 0) inv |= (1u << (-x0)) - 1u;
+                    if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);
+                    const u8 *row = src + (size_t)y * w;
+                    for (int i = 0; i < 32; i++)
+                        if (x0 + i >= 0 && x0 + i < w && row[x0 + i]) bits |= 1u << i;
+                }
+            }
+            if (idx < LH * LS) cur[idx] = (bits ^ km_first) | inv;
+        }
     }
     __syncthreads();
 
@@ -229,51 +252,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
 
     // ---- interior: bytes out + moments ----
+    // thread = (column word tid & 15, row tid >> 4), 16 rows per pass: no index division, the row pointer just advances;
+    // the first-order sums of a thread's <= 6 words fit 32 bits (x0, y < 2^24: checked at launch)
     unsigned long long m[6] = {0, 0, 0, 0, 0, 0};
-    u8 *dst = a.masks ? a.masks + (size_t)plane * w * h : nullptr;
-    const uint32_t rcp_i = (65536u + tww - 1) / tww;  // idx / tww for idx < TH * TWW
-    for (int idx = tid; idx < th * tww; idx += 256) {
-        const int r = (int)(((uint32_t)idx * rcp_i) >> 16), k = idx - r * tww;
-        const int y = ty * th + r, x0 = (tx * tww + k) * 32;
-        if (y >= h || x0 >= w) continue;
-        uint32_t bits = cur[(r + a.ht) * LS + (k + a.hwl)];
-        if (x0 + 32 > w) bits &= (1u << (w - x0)) - 1u;
-        if (dst) {
+    {
+        const int k = tid & 15;
+        const int x0 = (tx * tww + k) * 32;
+        const bool col_ok = k < tww && x0 < w;
+        const bool full = x0 + 32 <= w;
+        const uint32_t edge = (col_ok && !full) ? (1u << (w - x0)) - 1u : 0xFFFFFFFFu;
+        u8 *dst = a.masks ? a.masks + (size_t)plane * w * h : nullptr;
+        uint32_t m0 = 0, m1 = 0, m2 = 0;
+        if (col_ok) {
+            int y = ty * th + (tid >> 4);
+            const uint32_t *lp = cur + ((tid >> 4) + a.ht) * LS + (k + a.hwl);
             u8 *o = dst + (size_t)y * w + x0;
-            if (vec && x0 + 32 <= w) {
-                uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+            for (int r = tid >> 4; r < th && y < h; r += 16, y += 16, lp += 16 * LS, o += (size_t)16 * w) {
+                const uint32_t bits = *lp & edge;
+                if (dst) {
+                    if (vec && full) {
+                        uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint32_t nib = (bits >> (4 * q)) & 15u;
-                    o32[q] = __builtin_amdgcn_perm(0u, 0x0000FF00u, __umul24(nib, 0x00204081u) & 0x01010101u);
+                        for (int q = 0; q < 8; q++) {  // nibble -> four 0/255 bytes through the 16-entry table
+                            const uint32_t i4 = (q == 0 ? (bits << 2) : (bits >> (4 * q - 2))) & 60u;
+                            o32[q] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_lut) + i4);
+                        }
+                    } else {
+                        for (int i = 0; i < 32 && x0 + i < w; i++) o[i] = ((bits >> i) & 1u) ? 255 : 0;
+                    }
                 }
-            } else {
-                for (int i = 0; i < 32 && x0 + i < w; i++) o[i] = ((bits >> i) & 1u) ? 255 : 0;
+                const uint32_t cnt = __popc(bits);
+                const uint32_t bs = __popc(bits & 0xAAAAAAAAu) + 2 * __popc(bits & 0xCCCCCCCCu) + 4 * __popc(bits & 0xF0F0F0F0u) +
+                                    8 * __popc(bits & 0xFF00FF00u) + 16 * __popc(bits & 0xFFFF0000u);  // sum of bit indices
+                const uint32_t sx = __umul24((uint32_t)x0, cnt) + bs;
+                m0 += cnt;
+                m1 += sx;
+                m2 += __umul24((uint32_t)y, cnt);
+                if (a.second_order && bits) {
+                    // sum of squared bit indices i = sum_j 2^j b_j(i): i^2 = sum_j 4^j b_j + sum_{j<k} 2^(j+k+1) b_j b_k
+                    const uint32_t B[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
+                    unsigned long long bs2 = 0;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        bs2 += (unsigned long long)__popc(bits & B[j]) << (2 * j);
+#pragma unroll
+                        for (int kk = j + 1; kk < 5; kk++) bs2 += (unsigned long long)__popc(bits & B[j] & B[kk]) << (j + kk + 1);
+                    }
+                    m[3] += (unsigned long long)x0 * x0 * cnt + 2ull * x0 * bs + bs2;
+                    m[4] += (unsigned long long)y * sx;
+                    m[5] += (unsigned long long)y * y * cnt;
+                }
             }
         }
-        if (bits) {
-            const unsigned long long cnt = __popc(bits);
-            const unsigned long long bs = __popc(bits & 0xAAAAAAAAu) + 2 * __popc(bits & 0xCCCCCCCCu) + 4 * __popc(bits & 0xF0F0F0F0u) +
-                                          8 * __popc(bits & 0xFF00FF00u) + 16 * __popc(bits & 0xFFFF0000u);  // sum of bit indices
-            const unsigned long long sx = (unsigned long long)x0 * cnt + bs;
-            m[0] += cnt;
-            m[1] += sx;
-            m[2] += (unsigned long long)y * cnt;
-            if (a.second_order) {
-                // sum of squared bit indices i = sum_j 2^j b_j(i): i^2 = sum_j 4^j b_j + sum_{j<k} 2^(j+k+1) b_j b_k
-                const uint32_t B[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
-                unsigned long long bs2 = 0;
-#pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    bs2 += (unsigned long long)__popc(bits & B[j]) << (2 * j);
-#pragma unroll
-                    for (int k = j + 1; k < 5; k++) bs2 += (unsigned long long)__popc(bits & B[j] & B[k]) << (j + k + 1);
-                }
-                m[3] += (unsigned long long)x0 * x0 * cnt + 2ull * x0 * bs + bs2;
-                m[4] += (unsigned long long)y * sx;
-                m[5] += (unsigned long long)y * y * cnt;
-            }
-        }
+        m[0] = m0;
+        m[1] = m1;
+        m[2] = m2;
     }
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
@@ -386,6 +419,7 @@ hipError_t launch_bitmorph(const Plan &plan, const Group *d_groups, const u8 *d_
                            unsigned long long *d_mom, int w, int h, int planes, int second_order, hipStream_t stream)
 {
     if (planes <= 0 || w <= 0 || h <= 0) return hipSuccess;
+    if (w >= (1 << 24) || h >= (1 << 24)) return hipErrorInvalidValue;  // 24-bit multiplies in the moment sums
     Args a{};
     a.thresh = d_thresh;
     a.masks = d_masks;
