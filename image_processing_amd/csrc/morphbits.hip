@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint32_t km_first = mask_of(a.groups[0].kind);
     // PB words per thread at a time: all their global loads are issued before the first is used, so a thread waits for
     // HBM two or three times per tile instead of once per word
-    constexpr int PB = 4;
+    constexpr int PB = 5;
     for (int base = 0; base < LH * LS; base += 256 * PB) {
         uint32_t v[PB][8];
         int px0[PB], py[PB];
