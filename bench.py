@@ -46,12 +46,23 @@ def cpu_baseline(frames: np.ndarray, n_frames: int, threads: int) -> dict:
 
     one(0)
     t0 = time.perf_counter()
+    for i in range(8):  # the scalar figure: one thread
+        one(i)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
         list(ex.map(one, range(n_frames)))
     dt = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
+    except OSError:
+        pass
     return {"value": n_frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n_frames} frames of {W}x{H} BGR8, same chain, oracle/cpu_ref.c -O3 x86-64-v3, "
-                      f"{threads} threads (one frame per thread at a time); OpenCV itself is absent from the image"}
+                      f"{threads} threads (one frame per thread at a time); OpenCV itself is absent from the image",
+            "value_1_thread": 8 / dt1, "cpu_model": model}
 
 
 def main() -> None:
