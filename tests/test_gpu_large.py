@@ -117,3 +117,42 @@ def test_full_size_noise_vs_oracle(oracle, case):
                 got = [res[r][k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")]
                 assert got == [int(v) for v in exp["moments"][r]], (case, name, r)
             assert sum(int(m[0]) for m in exp["moments"]) > 0 or name == "polygon_path"
+
+
+@pytest.mark.parametrize("padded", [False, True])
+def test_pipelined_slots_stage_large_frames(oracle, padded):
+    """Three slots in flight at 1920x1200: the frames are staged by the helper threads (api.hip CopyPool), tight rows and
+    rows with a stride; every frame's mask and moments must equal the lone-frame path's (single-threaded staging), and
+    one of them the oracle's."""
+    w, h, n = 1920, 1200, 7
+    store = np.zeros((n, h, w + 40, 3), np.uint8)
+    frames = []
+    for i in range(n):
+        f = synth_frame(w, h, 100 + i)
+        if padded:
+            store[i, :, :w] = f
+            store[i, :, w:] = 255 - i  # the padding must never reach the device
+            frames.append(store[i, :, :w])
+        else:
+            frames.append(f)
+    morph = morph_tuples(ip.MORPH_BASELINE)
+    with ip.ImgProc(w, h, n_slots=3) as g:
+        g.set_pipeline(post_blur_k=5, morph=ip.MORPH_BASELINE, second_order=True)
+        g.set_ranges([DEFAULT_RANGE])
+        lone = []
+        for f in frames:  # nothing else in flight: single-threaded staging
+            r = g.process(np.ascontiguousarray(f))
+            lone.append((r, g.fetch_stage(0, L.STAGE_MASK)))
+        got = [None] * n
+        for i in range(n + 2):  # submit i while i-1 and i-2 are in flight
+            if i >= 2:
+                j = i - 2
+                got[j] = (g.wait(j % 3), g.fetch_stage(j % 3, L.STAGE_MASK))
+            if i < n:
+                g.submit(i % 3, frames[i])
+        for i in range(n):
+            assert got[i][0] == lone[i][0], i
+            assert (got[i][1] == lone[i][1]).all(), i
+    exp = oracle.chain(np.ascontiguousarray(frames[3]), post_blur_k=5, morph=morph, ranges=[DEFAULT_RANGE], stages=False)
+    assert (got[3][1] == exp["mask"][0]).all()
+    assert [got[3][0][0][k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")] == [int(v) for v in exp["moments"][0]]
