@@ -83,9 +83,15 @@ struct CopyPool {
     explicit CopyPool(int n)
     {
         for (auto &d : chunk_done) d.store(0);
-        for (int i = 0; i < n; i++) threads.emplace_back([this] { run(); });
+        try {
+            for (int i = 0; i < n; i++) threads.emplace_back([this] { run(); });
+        } catch (...) {  // a thread could not be started: end the ones that were (a joinable std::thread must not be destroyed)
+            shut_down();
+            throw;
+        }
     }
-    ~CopyPool()
+    ~CopyPool() { shut_down(); }
+    void shut_down()
     {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -93,6 +99,7 @@ struct CopyPool {
         }
         cv.notify_all();
         for (auto &t : threads) t.join();
+        threads.clear();
     }
     int helpers() const { return (int)threads.size(); }
     // Takes the next chunk of generation g, or -1 when none is left (or g is no longer the current frame: a helper
