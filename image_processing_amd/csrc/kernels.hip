@@ -34,6 +34,7 @@ __device__ __forceinline__ uint32_t hsv_pixel(int b, int g, int r, const int *sd
 // ---------------------------------------------------------------------------------------------
 // cvtColor BGR2HSV: 4 pixels (12 bytes) per lane, 3 dword loads / 3 dword stores when aligned.
 // ---------------------------------------------------------------------------------------------
+constexpr int HSV_ROWS = 32;
 __global__ __launch_bounds__(256) void k_bgr2hsv(const u8 *__restrict__ src, size_t sstride, u8 *__restrict__ dst,
                                                  size_t dstride, int w, int h, int bidx,
                                                  const int *__restrict__ tables, int vec_ok)
@@ -45,8 +46,10 @@ __global__ __launch_bounds__(256) void k_bgr2hsv(const u8 *__restrict__ src, siz
     __syncthreads();
     const int *sdiv = s_tab, *hdiv = s_tab + 256;
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= h || x4 >= w) return;
+    if (x4 >= w) return;
+    // HSV_ROWS rows per block (the 2 KB of tables are loaded once per block), 4 at a time
+#pragma unroll 2
+    for (int y = blockIdx.y * HSV_ROWS + threadIdx.y; y < min(h, (int)(blockIdx.y + 1) * HSV_ROWS); y += 4) {
     const u8 *s = src + (size_t)y * sstride + (size_t)x4 * 3;
     u8 *d = dst + (size_t)y * dstride + (size_t)x4 * 3;
     if (vec_ok && x4 + 4 <= w) {
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(256) void k_bgr2hsv(const u8 *__restrict__ src, siz
             d[3 * i + 2] = (u8)(o >> 16);
         }
     }
+    }
 }
 
 hipError_t launch_bgr2hsv(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int bidx,
@@ -78,7 +82,7 @@ hipError_t launch_bgr2hsv(const u8 *src, size_t sstride, u8 *dst, size_t dstride
 {
     if (w <= 0 || h <= 0) return hipSuccess;
     int vec_ok = ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0) && (sstride % 4 == 0) && (dstride % 4 == 0);
-    dim3 block(64, 4), grid((w + 255) / 256, (h + 3) / 4);
+    dim3 block(64, 4), grid((w + 255) / 256, (h + HSV_ROWS - 1) / HSV_ROWS);
     hipLaunchKernelGGL(k_bgr2hsv, grid, block, 0, stream, src, sstride, dst, dstride, w, h, bidx, d_tables, vec_ok);
     return hipGetLastError();
 }
