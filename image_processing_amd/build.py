@@ -11,7 +11,7 @@ LIB = os.path.join(LIBDIR, "libimgproc_hip.so")
 SOURCES = ["api.hip", "kernels.hip", "fused.hip", "fused_inst_plain_small.hip", "fused_inst_plain_large.hip",
            "fused_inst_bayer_small.hip", "fused_inst_bayer_large.hip", "morphbits.hip", "gauss.hip"]
 HEADERS = ["kernels.h", "fused.h", "fused_kernel.hpp", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread"]
 
 
 OBJDIR = os.path.join(LIBDIR, "obj")
