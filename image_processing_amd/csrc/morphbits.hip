@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const uint32_t *hsrc = cur;
             if (sp.lx != 0 || sp.hx != 0) {
                 // window AND of the bits x+lx .. x+hx on the 96-bit string (previous, this, next word): doubling
-                // (f_2n(x) = f_n(x) & f_n(x+n)), then the string is read at offset 32 + lx
+                // (f_2n(x) = f_n(x) & f_n(x+n)) up to the largest power of two in the window, then the string is read at
+                // offset 32 + lx and at the offset that ends the window at x+hx
                 const int len = sp.hx - sp.lx + 1, ex = 32 + sp.lx;  // len 1..65, ex 0..64
                 auto hpass = [&](auto cn, int base) {  // C words per thread starting at base + tid
                     constexpr int C = decltype(cn)::value;
@@ -186,11 +187,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                         step(have);
                         have *= 2;
                     }
-                    if (have < len) step(len - have);
+                    // a(x) = AND of `have` bits from x on (have = the largest power of two <= len); the window of len
+                    // bits is two of those, overlapping: one starting at x+lx, one ending at x+hx
+                    auto ext = [&](int j, int e) {  // the string read at bit offset e (0..64)
+                        return e >= 64 ? a2[j] : e >= 32 ? funnel(a2[j], a1[j], e - 32) : funnel(a1[j], a0[j], e);
+                    };
+                    const int ex2 = ex + len - have;
 #pragma unroll
                     for (int j = 0; j < C; j++) {
                         const int idx = base + tid + 256 * j;
-                        const uint32_t res = ex >= 64 ? a2[j] : ex >= 32 ? funnel(a2[j], a1[j], ex - 32) : funnel(a1[j], a0[j], ex);
+                        uint32_t res = ext(j, ex);
+                        if (have < len) res &= ext(j, ex2);
                         if (idx < h1) alt[idx] = res;
                     }
                 };
