@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         // surplus lanes compute but never store)
         const int n_it = (v1 - v0 + 255) >> 8;
         const int vfirst = v0 + tid, vlast = min(v0 + tid + 256 * (n_it - 1), v1 - 1);
+        bool cur_read_late = false;  // did a vertical pass read `cur` itself (a span without horizontal extent)?
         for (int si = 0; si < g.n_spans; si++) {
             const Span sp = g.spans[si];
             const uint32_t *hsrc = cur;
@@ -245,8 +246,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             default: vpass(std::integral_constant<int, 13>()); break;
             }
             if (hsrc == alt && si + 1 < g.n_spans) __syncthreads();  // alt is rewritten by the next span
+            cur_read_late |= hsrc == cur;
         }
-        __syncthreads();  // every read of cur is done
+        // the write-back below overwrites cur: its last readers were the horizontal passes (all behind a barrier
+        // already) unless a vertical pass read it directly
+        if (cur_read_late) __syncthreads();
 #pragma unroll
         for (int i = 0; i < WORDS_PER_THREAD; i++) {
             const int idx = v0 + tid + 256 * i;
