@@ -43,6 +43,8 @@ struct Slot {
     int valid_upto = -1;        // highest of IMGPROC_STAGE_BGR..THRESH that is materialised for the frame in the slot
     int masked_range = -1;      // d_masked holds frame & mask of this range (-1: not built)
     unsigned frame_epoch = 0;   // plan epoch the frame was submitted under
+    int nr = 0;                 // ranges / second-order flag the frame in flight was submitted with: imgproc_wait decodes
+    bool second = false;        // h_mom with these, not with whatever the plan says by then
 };
 
 // Staging of a submitted frame into the slot's pinned buffer by several threads: the frame is cut into row chunks that
@@ -182,10 +184,11 @@ struct Plan {
 
 struct imgproc_ctx {
     imgproc_config cfg{};
-    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream = nullptr;
     int *d_tables = nullptr;
     ipm::Group *d_groups = nullptr;  // device copy of plan.bm.groups (32 entries)
     std::vector<Slot> slots;
+    Slot work;  // scratch planes of the device-batch and single-stage paths (never visible to submit / wait / fetch_stage)
     Plan plan;
     struct Batch {  // one of the two in-flight device batches (imgproc_batch_enqueue / imgproc_batch_wait)
         unsigned long long *d_mom = nullptr, *h_mom = nullptr;
@@ -342,11 +345,13 @@ void free_slot(Slot &s)
     s = Slot();
 }
 
-int alloc_slot(imgproc_ctx *c, Slot &s)
+// staging = false: the context's own work slot (device batches, single-stage calls): no pinned frame buffer
+int alloc_slot(imgproc_ctx *c, Slot &s, bool staging = true)
 {
     const size_t px = (size_t)c->cfg.max_width * c->cfg.max_height;
-    HIPCHK(c, hipHostMalloc((void **)&s.h_in, px * 3, hipHostMallocDefault));
+    if (staging) HIPCHK(c, hipHostMalloc((void **)&s.h_in, px * 3, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&s.h_mom, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES, hipHostMallocDefault));
+    memset(s.h_mom, 0, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES);
     HIPCHK(c, hipMalloc((void **)&s.d_raw, px * 3));
     HIPCHK(c, hipMalloc((void **)&s.d_a, px * 3));
     HIPCHK(c, hipMalloc((void **)&s.d_b, px * 3));
@@ -511,7 +516,6 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
     auto build = [&]() -> int {
         HIPCHK(c, hipSetDevice(c->cfg.device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         // HSV reciprocal tables: cvRound == round-half-even == lrint
         int tab[512];
         tab[0] = tab[256] = 0;
@@ -539,7 +543,7 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
             int rc = alloc_slot(c, s);
             if (rc) return rc;
         }
-        return 0;
+        return alloc_slot(c, c->work, false);
     };
     int rc;
     try {
@@ -566,11 +570,11 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto &s : c->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         free_slot(s);
     }
+    free_slot(c->work);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_groups) (void)hipFree(c->d_groups);
     if (c->d_thresh_batch) (void)hipFree(c->d_thresh_batch);
@@ -585,7 +589,6 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
         if (b.ev_done) (void)hipEventDestroy(b.ev_done);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c->copy_pool;
     delete c;
 }
@@ -797,6 +800,8 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     s.in_flight = true;
     s.has_frame = true;
     s.frame_epoch = c->plan_epoch;
+    s.nr = p.bounds.n;
+    s.second = p.pipe.second_order != 0;
     s.valid_upto = path == 2 ? IMGPROC_STAGE_THRESH : -1;  // the fast paths leave no colour stage behind
     s.masked_range = (path == 2 && p.pipe.keep_stages) ? 0 : -1;
     return IMGPROC_OK;
@@ -812,8 +817,8 @@ IMGPROC_API int imgproc_wait(imgproc_ctx *c, int slot, imgproc_result *out)
     HIPCHK(c, hipEventSynchronize(s.ev_done));
     s.in_flight = false;
     memset(out, 0, sizeof *out);
-    out->n_ranges = c->plan.bounds.n;
-    for (int r = 0; r < out->n_ranges; r++) finish_moments(s.h_mom + 6 * r, out->r[r], c->plan.pipe.second_order != 0);
+    out->n_ranges = s.nr;  // as submitted: set_ranges / set_pipeline may have run since
+    for (int r = 0; r < out->n_ranges; r++) finish_moments(s.h_mom + 6 * r, out->r[r], s.second);
     return IMGPROC_OK;
 }
 
@@ -918,11 +923,7 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
         HIPCHK(c, hipEventRecord(bt.ev_done, c->stream));
         return IMGPROC_OK;
     }
-    Slot &s = c->slots[0];
-    if (s.in_flight) {
-        HIPCHK(c, hipEventSynchronize(s.ev_done));
-        s.in_flight = false;
-    }
+    Slot &s = c->work;  // stage-by-stage planes of the batch path; all its users run on c->stream, in order
     HIPCHK(c, hipMemsetAsync(bt.d_mom, 0, mom_bytes, c->stream));
     if (c->profiling) HIPCHK(c, hipEventRecord(bt.ev_k0, c->stream));
     if (p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
@@ -1117,11 +1118,7 @@ IMGPROC_API int imgproc_mask_and(imgproc_ctx *c, const uint8_t *bgr, size_t sstr
     if (rc) return rc;
     if (mstride < (size_t)w) return fail(c, IMGPROC_EINVAL, "mask stride too small");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    Slot &s = c->slots[0];
-    if (s.in_flight) {
-        HIPCHK(c, hipEventSynchronize(s.ev_done));
-        s.in_flight = false;
-    }
+    Slot &s = c->work;
     UPLOAD(c, c->d_s0, bgr, sstride, rowb, h);
     UPLOAD(c, s.d_m0, mask, mstride, (size_t)w, h);
     HIPCHK(c, ipk::launch_mask_and(c->d_s0, rowb, s.d_m0, (size_t)w, c->d_s1, rowb, w, h, c->stream));
@@ -1224,7 +1221,6 @@ IMGPROC_API int imgproc_synchronize(imgproc_ctx *c)
 {
     if (!c) return IMGPROC_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto &s : c->slots) HIPCHK(c, hipStreamSynchronize(s.stream));
     return IMGPROC_OK;

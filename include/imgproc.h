@@ -138,8 +138,8 @@ int imgproc_set_ranges(imgproc_ctx *ctx, int n, const int32_t (*lo)[3], const in
 
 /* ---- streaming path: what imageCb calls per frame (pose_estimate.cpp:175, objectPolygonPath.cpp:168)
  * submit copies `data` into the slot's pinned staging buffer (the caller may free it on return),
- * uploads on the copy stream and enqueues the chain; wait blocks until that slot's results are on
- * the host. */
+ * uploads on the slot's own stream and enqueues the chain behind it; wait blocks until that slot's
+ * results are on the host and reports them for the ranges the frame was submitted with. */
 int imgproc_submit(imgproc_ctx *ctx, int slot, const uint8_t *data, size_t stride, int w, int h);
 int imgproc_wait(imgproc_ctx *ctx, int slot, imgproc_result *out);
 int imgproc_fetch_stage(imgproc_ctx *ctx, int slot, int stage, int range, uint8_t *dst, size_t dst_stride);
