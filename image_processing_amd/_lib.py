@@ -61,6 +61,8 @@ _SIGS = {
                                         C.POINTER(Result)]),
     "imgproc_process_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                                C.c_int, C.c_void_p, C.POINTER(Result)]),
+    "imgproc_process_batch_device_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                                       C.c_int, C.c_void_p, C.POINTER(Result)]),
     "imgproc_batch_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_int]),
     "imgproc_batch_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),

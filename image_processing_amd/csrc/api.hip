@@ -24,6 +24,20 @@
 
 using ipk::u8;
 
+// ---- imgproc_process_batch_device_noalloc: the scratch of the one entry point that allocates nothing ----------------
+// Layout: [0, NA_MOM_BYTES) moment sums u64[frames * ranges][6]; [NA_MOM_BYTES, end) inRange planes handed from the front
+// kernel to the bit-plane kernel.  One copy per GPU, held until the process ends; every call on a GPU shares it.
+constexpr size_t NA_MOM_ENTRIES = 8192;                                   // frames x ranges per call
+constexpr size_t NA_MOM_BYTES = NA_MOM_ENTRIES * 6 * sizeof(unsigned long long);  // 393 216, a multiple of 256
+constexpr size_t NA_PLANE_BYTES = 32u << 20;                              // inRange planes: frames x ranges x w x h bytes
+constexpr size_t NA_SCRATCH_BYTES = NA_MOM_BYTES + NA_PLANE_BYTES;
+static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
+// `scratch` is a host-side stand-in in host code, not a device address: the per-device address is looked up once per
+// device (imgproc_create, with that device current) and only this pointer is ever used for kernel arguments / memsets / copies.
+constexpr int NA_MAX_DEVICES = 64;
+static unsigned char *g_scratch_ptr[NA_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
 namespace {
 
 struct Slot {
@@ -199,6 +213,8 @@ struct imgproc_ctx {
     int last_ticket = -1;  // the batch imgproc_last_kernel_ms reports on
     u8 *d_thresh_batch = nullptr;  // inRange planes of a device batch for the front + bit-plane path (grown on demand)
     size_t thresh_batch_bytes = 0;
+    unsigned char *na_scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress at create)
+    unsigned long long *h_na_mom = nullptr;  // pinned landing buffer of the no-allocation entry point (max_batch frames)
     u8 *d_s0 = nullptr, *d_s1 = nullptr;  // scratch for single-stage calls (max frame, 3 ch)
     unsigned long long *d_s_mom = nullptr;
     bool profiling = false;
@@ -538,6 +554,19 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
             HIPCHK(c, hipEventCreate(&b.ev_k1));
             HIPCHK(c, hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming));
         }
+        {  // this device's address of the no-allocation scratch: once per device, with the device current
+            if (c->cfg.device >= NA_MAX_DEVICES) return fail(c, IMGPROC_ENODEV, "device ordinal %d >= %d", c->cfg.device, NA_MAX_DEVICES);
+            std::lock_guard<std::mutex> lk(g_scratch_mu);
+            if (!g_scratch_ptr[c->cfg.device]) {
+                unsigned char *ptr = nullptr;
+                HIPCHK(c, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+                if (!ptr) return fail(c, IMGPROC_EHIP, "hipGetSymbolAddress(scratch) returned a null address");
+                g_scratch_ptr[c->cfg.device] = ptr;
+            }
+            c->na_scratch = g_scratch_ptr[c->cfg.device];
+            const size_t na_frames = (size_t)c->cfg.max_batch < NA_MOM_ENTRIES ? (size_t)c->cfg.max_batch : NA_MOM_ENTRIES;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_na_mom, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES * na_frames, hipHostMallocDefault));
+        }
         c->slots.resize(c->cfg.n_slots);
         for (auto &s : c->slots) {
             int rc = alloc_slot(c, s);
@@ -581,6 +610,7 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     if (c->d_s0) (void)hipFree(c->d_s0);
     if (c->d_s1) (void)hipFree(c->d_s1);
     if (c->d_s_mom) (void)hipFree(c->d_s_mom);
+    if (c->h_na_mom) (void)hipHostFree(c->h_na_mom);
     for (auto &b : c->batch) {
         if (b.d_mom) (void)hipFree(b.d_mom);
         if (b.h_mom) (void)hipHostFree(b.h_mom);
@@ -992,6 +1022,57 @@ IMGPROC_API int imgproc_process_batch_device(imgproc_ctx *c, const void *d_frame
     int rc = imgproc_batch_enqueue(c, d_frames, frame_stride, row_stride, w, h, n, d_masks, 0);
     if (rc) return rc;
     return imgproc_batch_wait(c, 0, out);
+}
+
+// The one entry point that allocates nothing (include/imgproc.h): imgproc_process_batch_device with the library's
+// scratch (moment sums, the inRange planes between the front kernel and the bit-plane kernel) in the per-GPU static
+// array `scratch` instead of hipMalloc'ed buffers.  No hipMalloc / hipFree / hipHostMalloc on this path: the pinned
+// landing buffer and the scratch address were set up by imgproc_create.
+IMGPROC_API int imgproc_process_batch_device_noalloc(imgproc_ctx *c, const void *d_frames, size_t frame_stride,
+                                                     size_t row_stride, int w, int h, int n, void *d_masks,
+                                                     imgproc_result *out)
+{
+    if (!c || !d_frames || !out || n < 0) return IMGPROC_EINVAL;
+    if (n == 0) return IMGPROC_OK;
+    int rc = check_frame(c, w, h, row_stride);
+    if (rc) return rc;
+    const Plan &p = c->plan;
+    const int nr = p.bounds.n;
+    const size_t px = (size_t)w * h;
+    if (n > c->cfg.max_batch) return fail(c, IMGPROC_ESIZE, "batch %d > max_batch %d", n, c->cfg.max_batch);
+    if ((size_t)n * nr > NA_MOM_ENTRIES)
+        return fail(c, IMGPROC_ESIZE, "no-allocation path: %d frames x %d ranges > %zu moment entries", n, nr, NA_MOM_ENTRIES);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    unsigned long long *d_mom = reinterpret_cast<unsigned long long *>(c->na_scratch);
+    u8 *d_planes = c->na_scratch + NA_MOM_BYTES;
+    const size_t mom_bytes = sizeof(unsigned long long) * 6 * nr * (size_t)n;
+    const bool chain = p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks);
+    const bool front = !chain && p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks);
+    if (!chain && !front)
+        return fail(c, IMGPROC_EUNSUPPORTED, "no-allocation path: this pipeline / frame shape runs stage by stage (%dx%d)", w, h);
+    if (front && (size_t)n * nr * px > NA_PLANE_BYTES)
+        return fail(c, IMGPROC_ESIZE, "no-allocation path: %d frames x %d ranges x %dx%d inRange planes > %zu scratch bytes", n, nr,
+                    w, h, NA_PLANE_BYTES);
+    // the array keeps the last call's contents: the sums must start at zero (the planes are fully rewritten)
+    HIPCHK(c, hipMemsetAsync(d_mom, 0, mom_bytes, c->stream));
+    if (chain) {
+        HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks, d_mom,
+                                    c->d_tables, c->stream));
+    } else {
+        HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, d_planes, nullptr,
+                                    c->d_tables, c->stream));
+        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, d_planes, (u8 *)d_masks, d_mom, w, h, n * nr, p.pipe.second_order,
+                                       c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_na_mom, d_mom, mom_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) {
+        memset(&out[i], 0, sizeof out[i]);
+        out[i].n_ranges = nr;
+        for (int r = 0; r < nr; r++)
+            finish_moments(c->h_na_mom + ((size_t)i * nr + r) * 6, out[i].r[r], p.pipe.second_order != 0);
+    }
+    return IMGPROC_OK;
 }
 
 // ================================================================================================

@@ -160,6 +160,18 @@ int imgproc_batch_enqueue(imgproc_ctx *ctx, const void *d_frames, size_t frame_s
                           int n, void *d_masks, int ticket);
 int imgproc_batch_wait(imgproc_ctx *ctx, int ticket, imgproc_result *out);
 
+/* imgproc_process_batch_device for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results
+ * as imgproc_process_batch_device, but the library's scratch (the moment sums; the inRange planes between the
+ * front kernel and the bit-plane kernel) lives in a static per-GPU device array of 32 MiB + 384 KiB instead of
+ * allocated buffers, and the call makes no hipMalloc / hipFree / hipHostMalloc.  Limits: n <= max_batch,
+ * n * n_ranges <= 8192, and for pipelines that run as front kernel + bit-plane morphology
+ * n * n_ranges * w * h <= 32 MiB (IMGPROC_ESIZE beyond); pipelines or frame shapes that run stage by stage
+ * return IMGPROC_EUNSUPPORTED.  Synchronous (returns with `out` filled).  Every call on a GPU shares that GPU's
+ * array: calls that overlap on one GPU (two contexts, two threads) race. */
+int imgproc_process_batch_device_noalloc(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride,
+                                         size_t row_stride, int w, int h, int n, void *d_masks, imgproc_result *out);
+
 /* ---- single stages on host buffers: one entry point per cv:: call on the path ----------------- */
 /* cvtColor(src, dst, CV_BGR2HSV)  objectPolygonPath.cpp:183, pose_estimate.cpp:203; encoding BGR8|RGB8 */
 int imgproc_cvt_bgr2hsv(imgproc_ctx *ctx, const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride,
