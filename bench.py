@@ -1,54 +1,143 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json): frames/s of the full fused chain (5x5 Gaussian on HSV, HSV inRange,
-3x3 erode + dilate, moments) on 1920x1200 BGR8 frames, a device-resident batch of 256 frames per GPU per
-step, plus the achieved HBM GB/s of the chain kernel against the MI355X roofline and the CPU port of
-the same chain timed on the host's cores.
+"""Benchmark of the per-frame pixel chain (BASELINE.json).  Default = the headline configuration:
+frames/s of the full fused chain (5x5 Gaussian on HSV, HSV inRange, 3x3 erode + dilate, moments) on
+1920x1200 BGR8 frames, a device-resident batch of 256 frames per GPU per step, plus the achieved HBM
+GB/s of the chain kernel against the MI355X roofline and the CPU port of the same chain timed on the
+host's cores.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
+
+--gpus N > 1 without WORLD_SIZE in the environment: this process (which never touches the GPU) starts N
+rank processes itself, one per GPU, and relays rank 0's JSON line.  Under torch.distributed.run
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the launcher and nothing is spawned.
 
 One process per GPU; frames are sharded across ranks with NO data-path collective (the path has no
-cross-frame step), so scaling is weak: every rank processes its own 256-frame batch per step.  The only
-inter-rank traffic is the timing barrier / max-reduction (control plane, gloo).
+cross-frame step).  The only inter-rank traffic is the timing barrier / max-reduction and the host-side
+gather of the per-frame moments (control plane, gloo).
+
+Configurations (BASELINE.json `configs`):
+  c2  configs[1]  1920x1200 BGR8, 256 frames per GPU per step, G5 -> inRange -> E3 -> D3 -> moments        (weak scaling)
+  c3  configs[2]  2448x2048 BayerRG8, demosaic inside the chain kernel, 64 frames per GPU per step; plus the
+                  streamed leg (host frames -> pinned slots -> H2D -> chain), reported beside it, never as `value`
+  c4  configs[3]  3840x2160 BGR8, a 4096-frame stream per step cut into contiguous blocks by shard_bounds,
+                  per-frame centroids gathered on rank 0                                                      (strong scaling)
+  c5  configs[4]  7680x4320 BGR8, 15x15 Gaussian + 9x9 elliptical erode/dilate + 8 ranges, 4 frames per GPU per step
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, BATCH = 1920, 1200, 256
-ALGO_BYTES_PER_FRAME = W * H * 4  # 3 B/px read + 1 B/px mask written
 PREROLL_S = 0.15  # untimed steady-state pre-roll before the warmup steps (GPU clock ramp)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# wave64 VALU: 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz, one op per lane and cycle
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
+STREAM_FRAMES_C4 = 4096
 
 
-def cpu_baseline(frames: np.ndarray, n_frames: int, threads: int) -> dict:
-    """Times the CPU port (oracle/cpu_ref.c built -O3) of the same chain on a bounded sample."""
+def config_table():
+    import image_processing_amd as ip
+    from image_processing_amd import _lib as L
+    from image_processing_amd.synth import DEFAULT_RANGE
+
+    bands = [(20 * i, 20 * i + 19) for i in range(8)]
+    return {
+        "c2": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+                   pipe=dict(post_blur_k=5, morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE],
+                   metric="frames/sec at 1920x1200 BGR8, full chain (5x5 Gaussian, HSV inRange, 3x3 erode+dilate, moments)",
+                   workload="configs[1]: 1920x1200 BGR8, device-resident batch of 256 frames per GPU per step, post-HSV 5x5 "
+                            "Gaussian + inRange + erode3 + dilate3 + moments, masks written to HBM"),
+        "c3": dict(w=2448, h=2048, enc=L.ENC_BAYER_RGGB8, batch=64, uniq=4, bpp=2, scaling="weak", hue_bands=((100, 130),),
+                   pipe=dict(post_blur_k=5, morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE],
+                   metric="frames/sec at 2448x2048 BayerRG8, demosaic + full chain (device-resident leg)",
+                   workload="configs[2]: 2448x2048 BayerRG8 mosaics, device-resident batch of 64 frames per GPU per step, demosaic "
+                            "inside the chain kernel + 5x5 Gaussian + inRange + erode3 + dilate3 + moments; the streamed leg "
+                            "(pinned slots, H2D per frame) is reported under `streamed`"),
+        "c4": dict(w=3840, h=2160, enc=L.ENC_BGR8, batch=64, uniq=8, bpp=4, scaling="strong", hue_bands=((100, 130),),
+                   pipe=dict(post_blur_k=5, morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE], stream=STREAM_FRAMES_C4,
+                   metric="frames/sec at 3840x2160 BGR8, 4096-frame stream sharded across the GPUs, full chain",
+                   workload="configs[3]: one step = a 4096-frame 3840x2160 BGR8 stream (a pool of 64 device-resident frames, "
+                            "cycled) cut into contiguous per-rank blocks by shard_bounds, device batches of 64 frames, two in "
+                            "flight; per-frame centroids gathered on rank 0 by frame id after the timed region"),
+        "c5": dict(w=7680, h=4320, enc=L.ENC_BGR8, batch=4, uniq=1, bpp=11, scaling="weak", hue_bands=tuple(bands),
+                   pipe=dict(post_blur_k=15, morph=[ip.E(9, L.ELLIPSE), ip.D(9, L.ELLIPSE)]),
+                   ranges=[((lo, 100, 80), (hi, 255, 255)) for lo, hi in bands],
+                   metric="frames/sec at 7680x4320 BGR8, stress chain (15x15 Gaussian, 8 ranges, 9x9 elliptical erode+dilate, moments)",
+                   workload="configs[4] operators: 7680x4320 BGR8, device-resident batch of 4 frames per GPU per step, HSV + 15x15 "
+                            "Gaussian + 8 inRange planes + 9x9 ellipse erode + dilate + 8 moment sets, 8 masks written"),
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# parent: start one rank process per GPU (never initialises HIP itself)
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int, argv: list[str]) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), BENCH_SPAWNED="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        bad = []
+        while not bad and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:  # a rank died: the others would wait for it in the next barrier until gloo's timeout -- end exactly those
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
+    if bad:
+        print(f"bench.py: rank processes failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline leg (rank 0, N = 1): the oracle, as the thing timed beside the GPU path -- never part of it
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg: dict, frames, threads: int, budget_s: float = 12.0) -> dict:
+    """Times the CPU port (oracle/cpu_ref.c built -O3) of the same chain on a bounded sample of the same frames."""
     from concurrent.futures import ThreadPoolExecutor
 
-    import image_processing_amd as ip
-    from image_processing_amd.synth import DEFAULT_RANGE
     from oracle import Oracle
 
     orc = Oracle(fast=True)
-    morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in ip.MORPH_BASELINE]
+    pipe = cfg["pipe"]
+    morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in pipe["morph"]]
+    enc = cfg["enc"]
 
     def one(i):
-        return orc.chain(frames[i % len(frames)], post_blur_k=5, morph=morph, ranges=[DEFAULT_RANGE], stages=False)["moments"]
+        return orc.chain(frames[i % len(frames)], encoding=enc, pre_blur_k=pipe.get("pre_blur_k", 0),
+                         post_blur_k=pipe.get("post_blur_k", 0), morph=morph, ranges=cfg["ranges"], stages=False)["moments"]
 
-    one(0)
     t0 = time.perf_counter()
-    for i in range(8):  # the scalar figure: one thread
-        one(i)
-    dt1 = time.perf_counter() - t0
+    one(0)
+    t1 = time.perf_counter() - t0  # one frame on one thread
+    per_thread = max(1, min(8, int(budget_s / max(t1, 1e-3))))
+    n_frames = per_thread * threads
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
         list(ex.map(one, range(n_frames)))
@@ -60,71 +149,137 @@ def cpu_baseline(frames: np.ndarray, n_frames: int, threads: int) -> dict:
     except OSError:
         pass
     return {"value": n_frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n_frames} frames of {W}x{H} BGR8, same chain, oracle/cpu_ref.c -O3 x86-64-v3, "
-                      f"{threads} threads (one frame per thread at a time); OpenCV itself is absent from the image",
-            "value_1_thread": 8 / dt1, "cpu_model": model}
+            "sample": f"{n_frames} frames of {cfg['w']}x{cfg['h']}, same chain, oracle/cpu_ref.c -O3 x86-64-v3 (scalar restatement of "
+                      f"OpenCV's arithmetic, not a SIMD OpenCV build), {threads} threads, one frame per thread at a time; "
+                      "OpenCV itself is absent from the image",
+            "value_1_thread": 1.0 / t1, "cpu_model": model}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")
-    ap.add_argument("--check", action="store_true", help="also verify one frame of the batch against the oracle")
-    args = ap.parse_args()
+def kernel_name(cfg: dict, plan: str) -> str:
+    from image_processing_amd import _lib as L
 
-    import torch
+    if plan.startswith("fused chain kernel"):
+        pipe, nr = cfg["pipe"], len(cfg["ranges"])
+        cap = nr if nr <= 2 else 4 if nr <= 4 else 8
+        bayer = "true" if cfg["enc"] == L.ENC_BAYER_RGGB8 else "false"
+        return (f"ipf::k_fused_chain<{3 if pipe.get('pre_blur_k', 0) == 3 else 1},{5 if pipe.get('post_blur_k', 0) == 5 else 1},"
+                f"false,{cap},3,false,0,{bayer}>")
+    return f"all chain kernels of one batch ({plan})"
+
+
+def offline_counters(name: str):
+    """PMC figures of this configuration's chain kernel(s) from the committed rocprofv3 --pmc passes (profiles/): HBM
+    bytes and VALU instructions per launch.  They are properties of the kernel build and the workload shape, not of
+    this run: labelled as such in the JSON, None when the file is absent or does not cover the configuration."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        return json.load(f).get(name), os.path.relpath(path, ROOT)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(args) -> None:
+    import numpy as np
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dry = os.environ.get("BENCH_DRY_RUN") == "1"  # CPU rehearsal of the launch / rendezvous / relay logic: no GPU work
+
+    import torch
+
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import image_processing_amd as ip
+    from image_processing_amd import _lib as L
+    from image_processing_amd.shard import centroids, gather_by_frame, shard_bounds
+    from image_processing_amd.synth import synth_bayer_rggb, synth_frame
+
+    cfg = config_table()[args.config]
+    W, H, enc, pool_n, uniq = cfg["w"], cfg["h"], cfg["enc"], cfg["batch"], cfg["uniq"]
+    cn = 1 if enc == L.ENC_BAYER_RGGB8 else 3
+    nr = len(cfg["ranges"])
+    algo_bytes = W * H * cfg["bpp"]
+    strong = cfg["scaling"] == "strong"
+
+    # the batches of one step: (offset into the device frame pool, frames, first stream frame id)
+    if strong:
+        a, b = shard_bounds(cfg["stream"], rank, world)
+        batches, cur = [], a
+        while cur < b:
+            n = min(pool_n - cur % pool_n, b - cur)
+            batches.append((cur % pool_n, n, cur))
+            cur += n
+        frames_per_step_total = cfg["stream"]
+    else:
+        a, b = rank * pool_n, (rank + 1) * pool_n
+        batches = [(0, pool_n, a)]
+        frames_per_step_total = pool_n * world
+    n_local = b - a
+
+    if dry:
+        dt = 1e-3 * (rank + 1) * args.steps
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        local = np.zeros((n_local, nr, 3), np.int64)
+        local[:, :, 0] = 1
+        local[:, :, 1] = np.arange(a, b)[:, None]
+        gathered = gather_by_frame(local, frames_per_step_total, rank, world, dist)
+        if rank == 0:
+            assert (gathered[:, 0, 1] == np.arange(frames_per_step_total)).all()
+            print(json.dumps({"metric": cfg["metric"], "value": frames_per_step_total * args.steps / dt, "unit": "frames/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "u8",
+                              "data": "dry run: no GPU work", "config": {"workload": cfg["workload"], "dry_run": True}}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     if os.environ.get("BENCH_ALL_RANKS_ON_GPU0") == "1":  # rehearsal of the N>1 path on a one-GPU box
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    import image_processing_amd as ip
-    from image_processing_amd.synth import DEFAULT_RANGE, synth_batch
-
-    # synthetic frames: 8 unique seeded frames per rank, replicated (rolled) to 256 distinct HBM buffers
-    uniq = 8
-    base_np = synth_batch(W, H, uniq, seed=0x1A6E5EED + 1000 * rank)
+    # synthetic frames: `uniq` seeded frames per rank, replicated (rolled) to a pool of distinct HBM buffers
+    seed = 0x1A6E5EED + 1000 * rank
+    if cn == 1:
+        base_np = np.stack([synth_bayer_rggb(W, H, i, seed=seed, hue_bands=cfg["hue_bands"]) for i in range(uniq)])
+    else:
+        base_np = np.stack([synth_frame(W, H, i, seed=seed, hue_bands=cfg["hue_bands"]) for i in range(uniq)])
     base = torch.from_numpy(base_np).to(dev)
-    frames = torch.empty((BATCH, H, W, 3), dtype=torch.uint8, device=dev)
-    for i in range(BATCH):
-        frames[i] = torch.roll(base[i % uniq], i // uniq, dims=0)
-    masks = torch.empty((BATCH, 1, H, W), dtype=torch.uint8, device=dev)
+    frames = torch.empty((pool_n,) + tuple(base.shape[1:]), dtype=torch.uint8, device=dev)
+    for i in range(pool_n):
+        frames[i] = torch.roll(base[i % uniq], (2 if cn == 1 else 1) * (i // uniq), dims=0)  # even shifts keep the mosaic phase
+    masks = torch.empty((pool_n, nr, H, W), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+    frame_bytes, row_bytes = H * W * cn, W * cn
 
-    g = ip.ImgProc(W, H, device=local_rank, n_slots=1, max_batch=BATCH)
-    g.set_pipeline(post_blur_k=5, morph=ip.MORPH_BASELINE, force_unfused=args.unfused)
-    g.set_ranges([DEFAULT_RANGE])
+    g = ip.ImgProc(W, H, device=local_rank, n_slots=1, max_batch=pool_n)
+    g.set_pipeline(encoding=enc, force_unfused=args.unfused, **cfg["pipe"])
+    g.set_ranges(cfg["ranges"])
     g.set_profiling(True)
-    fused = g.is_fused
+    plan = g.plan
 
-    from image_processing_amd import _lib as L
+    # the C ABI fills these host arrays with the per-frame moments / centroids; two, because two batches are in flight:
+    # batch k+1 is put on the stream before batch k's results are waited for, so the GPU never idles between them
+    raws = [(L.Result * pool_n)(), (L.Result * pool_n)()]
 
-    # the C ABI fills these host arrays with the per-frame moments / centroids; two, because two steps are in flight:
-    # step i+1 is put on the stream before step i's results are waited for, so the GPU never idles between steps
-    raws = [(L.Result * BATCH)(), (L.Result * BATCH)()]
+    def enqueue(k):
+        off, n, _ = batches[k % len(batches)]
+        g.batch_enqueue(k & 1, frames.data_ptr() + off * frame_bytes, frame_bytes, row_bytes, W, H, n, masks.data_ptr())
 
-    def enqueue(i):
-        g.batch_enqueue(i & 1, frames.data_ptr(), H * W * 3, W * 3, W, H, BATCH, masks.data_ptr())
-
-    def wait(i):
-        return g.batch_wait(i & 1, raw=raws[i & 1])
-
-    def step():
-        enqueue(0)
-        return wait(0)
+    def wait(k):
+        return g.batch_wait(k & 1, raw=raws[k & 1])
 
     def fence():
         g.synchronize()
@@ -134,22 +289,37 @@ def main() -> None:
 
     # The GPU's clocks take tens of milliseconds of sustained load to settle (measured: the same kernel runs 0.87 ms in
     # a 23-step run and 0.78 ms from the ~40th step on).  The metric is steady-state throughput, so the device is kept
-    # busy with the same step for PREROLL_S before the W warmup steps; nothing of it is timed or reported.
+    # busy with the same work for PREROLL_S before the W warmup steps; nothing of it is timed or reported.
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < PREROLL_S:
-        step()
-    for _ in range(args.warmup):
-        res = step()
+        enqueue(0)
+        wait(0)
+    nb = len(batches)
+    for k in range(args.warmup * nb):
+        enqueue(k)
+        wait(k)
     fence()
-    kernel_ms = []
+    kernel_ms, kernel_frames = [], []
+    local = np.zeros((n_local, nr, 3), np.int64)
+    total = args.steps * nb
+
+    def collect(k):
+        res = wait(k)
+        kernel_ms.append(g.last_kernel_ms())  # HIP events recorded on the library's stream around the chain kernel(s)
+        off, n, first = batches[k % nb]
+        kernel_frames.append(n)
+        if k >= total - nb:  # the last step's results, by stream frame id
+            for i in range(n):
+                for r in range(nr):
+                    m = res[i].r[r]
+                    local[first - a + i, r] = (m.m00, m.m10, m.m01)
+
     t0 = time.perf_counter()
-    for i in range(args.steps):  # every step's results reach the host inside the timed region
-        enqueue(i)
-        if i:
-            res = wait(i - 1)
-            kernel_ms.append(g.last_kernel_ms())  # HIP events recorded on the library's stream around the chain kernel
-    res = wait(args.steps - 1)
-    kernel_ms.append(g.last_kernel_ms())
+    for k in range(total):  # every batch's results reach the host inside the timed region
+        enqueue(k)
+        if k:
+            collect(k - 1)
+    collect(total - 1)
     g.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -159,63 +329,143 @@ def main() -> None:
         dt = float(t.item())
         dist.barrier()
 
-    # host-side gather of the last step's per-frame moments, ordered by global frame id (rank-major blocks).
-    # Outside the timed region: the data path itself has no inter-rank step.
-    from image_processing_amd.shard import centroids, gather_by_frame
-
-    local = np.array([[res[i].r[0].m00, res[i].r[0].m10, res[i].r[0].m01] for i in range(BATCH)], np.int64)
-    gathered = gather_by_frame(local, BATCH * world, rank, world, dist)
-    n_found = int((centroids(gathered)[:, 0] >= 0).sum()) if rank == 0 else 0
+    # host-side gather of the last step's per-frame moments, ordered by global frame id.  Outside the timed region: the
+    # data path itself has no inter-rank step.
+    t_g = time.perf_counter()
+    gathered = gather_by_frame(local, frames_per_step_total, rank, world, dist)
+    gather_ms = (time.perf_counter() - t_g) * 1e3
+    n_found = int((centroids(gathered)[:, 0, 0] >= 0).sum()) if rank == 0 else 0
 
     if args.check and rank == 0:
         from oracle import Oracle
 
-        i = 9
-        f = frames[i].cpu().numpy()
-        morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in ip.MORPH_BASELINE]
-        exp = Oracle(fast=True).chain(f, post_blur_k=5, morph=morph, ranges=[DEFAULT_RANGE], stages=False)
-        assert (masks[i, 0].cpu().numpy() == exp["mask"][0]).all(), "bench mask != oracle"
-        assert [getattr(res[i].r[0], k) for k in ("m00", "m10", "m01")] == [int(v) for v in exp["moments"][0][:3]]
+        i = min(9, batches[-1][1] - 1)
+        f = frames[batches[-1][0] + i].cpu().numpy()
+        pipe = cfg["pipe"]
+        morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in pipe["morph"]]
+        exp = Oracle(fast=True).chain(f, encoding=enc, pre_blur_k=pipe.get("pre_blur_k", 0), post_blur_k=pipe.get("post_blur_k", 0),
+                                      morph=morph, ranges=cfg["ranges"], stages=False)
+        got = masks[i].cpu().numpy()
+        for r in range(nr):
+            assert (got[r] == exp["mask"][r]).all(), f"bench mask of range {r} != oracle"
+            idx = batches[-1][2] - a + i
+            assert [int(v) for v in local[idx, r]] == [int(v) for v in exp["moments"][r][:3]], "bench moments != oracle"
 
     if rank == 0:
-        total_frames = BATCH * args.steps * world
-        fps = total_frames / dt
-        k_ms = float(np.mean([m for m, _ in kernel_ms]))
+        fps = frames_per_step_total * args.steps / dt
+        ms_sum = float(sum(m for m, _ in kernel_ms))
+        k_ms = ms_sum / len(kernel_ms)  # per batch launch (one chain kernel on the fused path)
         launches = kernel_ms[-1][1]
-        achieved = BATCH * ALGO_BYTES_PER_FRAME / (k_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-        # --pmc runs of this same command, gfx950 x2 correction on the read side); null when the file is absent
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_e_traffic.json")
-        if fused and os.path.exists(tpath):
-            with open(tpath) as tf:
-                traffic = json.load(tf).get("hbm_bytes_per_launch")
+        bytes_per_launch = algo_bytes * (sum(kernel_frames) / len(kernel_frames))
+        achieved = algo_bytes * sum(kernel_frames) / (ms_sum * 1e-3) / 1e9
+        fused = plan.startswith("fused chain kernel")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None, "traffic_source": None,
+                "kernel": kernel_name(cfg, plan), "kernel_ms_per_launch": k_ms if fused else None,
+                "kernel_ms_per_batch": k_ms, "launches_per_batch": launches,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_px": cfg["bpp"]}
+        pmc, src = offline_counters(args.config if not args.unfused else "none")
+        if pmc and abs(pmc.get("frames_per_launch", 0) - bytes_per_launch / algo_bytes) < 0.5:
+            # HBM bytes from rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE, separate runs, the
+            # guide's gfx950 corrections); VALU instructions likewise -- offline figures of the kernel, not of this run
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["traffic_source"] = f"{src} (offline rocprofv3 --pmc passes of this command, kernel build {pmc.get('lib_sha16')})"
+            if pmc.get("valu_insts_per_launch"):
+                lane_ops = pmc["valu_insts_per_launch"] * 64 / (k_ms * 1e-3)
+                roof["valu"] = {"achieved_lane_ops_per_s": lane_ops, "peak": VALU_PEAK_LANE_OPS, "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                                "valu_insts_per_launch": pmc["valu_insts_per_launch"],
+                                "lane_ops_per_px": pmc["valu_insts_per_launch"] * 64 / (bytes_per_launch / cfg["bpp"]),
+                                "insts_source": roof["traffic_source"],
+                                "note": "the kernel is VALU-issue-bound: this fraction, not the HBM one, is what is saturated"}
         out = {
-            "metric": "frames/sec at 1920x1200 BGR8, full chain (5x5 Gaussian, HSV inRange, 3x3 erode+dilate, moments)",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": cfg["metric"], "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1920x1200 BGR8, device-resident batch of 256 frames per GPU per step, "
-                                   "post-HSV 5x5 Gaussian + inRange + erode3 + dilate3 + moments, masks written to HBM; "
-                                   "two steps in flight (results of step i are collected after step i+1 is enqueued)",
-                       "frames_per_step_per_gpu": BATCH, "width": W, "height": H, "untimed_preroll_s": PREROLL_S,
-                       "path": "fused" if fused else f"stage-by-stage ({launches} launches per step)",
-                       "sharding": f"frames x{world} ranks, no collective; {BATCH * world} centroids gathered on rank 0 "
-                                   f"after the timed region ({n_found} with an object)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "ipf::k_fused_chain<1,5,false,1,3,false,0,false>" if fused else "all stage kernels of one step",
-                         "kernel_ms_per_launch": k_ms, "algorithmic_bytes_per_launch": BATCH * ALGO_BYTES_PER_FRAME},
-            "achieved_gbps_whole_job": fps * ALGO_BYTES_PER_FRAME / 1e9,
+            "config": {"workload": cfg["workload"] + "; two batches in flight (results of batch k are collected after batch k+1 "
+                                                    "is enqueued)",
+                       "name": args.config, "frames_per_step": frames_per_step_total, "frames_per_batch": pool_n, "width": W,
+                       "height": H, "n_ranges": nr, "untimed_preroll_s": PREROLL_S,
+                       "path": plan if not args.unfused else f"stage-by-stage ({launches} launches per batch)",
+                       "sharding": f"frames x{world} ranks ({cfg['scaling']}), no collective; {frames_per_step_total} centroids "
+                                   f"gathered on rank 0 after the timed region in {gather_ms:.2f} ms ({n_found} with an object)"},
+            "roofline": roof,
+            "achieved_gbps_whole_job": fps * algo_bytes / 1e9,
         }
+        if args.config == "c3" and world == 1 and not args.no_streamed:
+            out["streamed"] = streamed_leg(cfg, base_np, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(base_np, 8 * threads, threads)
+            out["cpu_baseline"] = cpu_baseline(cfg, base_np, threads)
         print(json.dumps(out), flush=True)
     g.close()
     if dist is not None:
         dist.destroy_process_group()
 
 
+def streamed_leg(cfg: dict, base_np, device: int, n: int = 96, slots: int = 3) -> dict:
+    """configs[2]'s upload leg: host frames -> the slots' pinned staging buffers -> hipMemcpyAsync on each slot's stream,
+    overlapped with the chain kernel of the slot before -> 48 B of moments back (imgproc_process_batch).  PCIe-bound;
+    reported beside the device-resident number, never as `value`."""
+    import numpy as np
+
+    import image_processing_amd as ip
+    from image_processing_amd import _lib as L
+
+    W, H = cfg["w"], cfg["h"]
+    host = np.ascontiguousarray(np.concatenate([base_np] * (n // len(base_np))))
+    with ip.ImgProc(W, H, device=device, n_slots=slots) as g:
+        g.set_pipeline(encoding=cfg["enc"], **cfg["pipe"])
+        g.set_ranges(cfg["ranges"])
+        res = (L.Result * len(host))()
+
+        def run():
+            rc = g.lib.imgproc_process_batch(g._ctx, host.ctypes.data, host.strides[0], host.strides[1], W, H, len(host), res)
+            assert rc == 0, g.lib.imgproc_last_error(g._ctx)
+
+        run()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        dt = (time.perf_counter() - t0) / reps
+    fps = len(host) / dt
+    return {"value": fps, "unit": "frames/s", "pcie_gbps": fps * host[0].nbytes / 1e9, "slots": slots, "frames": len(host),
+            "note": "host frames -> pinned staging (memcpy by the caller + 3 helper threads) -> H2D per slot stream -> chain kernel -> "
+                    "moments; includes the staging memcpy; PCIe Gen5 x16 practical peak ~55 GB/s"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streamed", action="store_true", help="c3: skip the streamed (PCIe) leg")
+    ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")
+    ap.add_argument("--check", action="store_true", help="also verify one frame of the last batch against the oracle")
+    args = ap.parse_args()
+    defaults = {"c2": (100, 20), "c3": (50, 10), "c4": (5, 1), "c5": (20, 4)}[args.config]
+    if args.steps is None:
+        args.steps = defaults[0]
+    if args.warmup is None:
+        args.warmup = defaults[1]
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the ranks from here.  This process has not imported torch or touched HIP and
+        # never will; the ranks are fresh child processes, not re-execs.
+        argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config]
+        argv += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
+        argv += ["--unfused"] if args.unfused else []
+        argv += ["--check"] if args.check else []
+        return spawn_ranks(args.gpus, argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: using the launcher's world size", file=sys.stderr)
+    run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

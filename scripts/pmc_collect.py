@@ -1,0 +1,47 @@
+"""Turns the passes of scripts/prof_config.sh into one JSON: per kernel of the library (ipf:: / ipm:: / ipk::) the
+rocprofv3 kernel-trace average duration and the mean per dispatch of every counter collected.
+usage: python3 scripts/pmc_collect.py gpurun_out/<tag> <config>"""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import re
+import sys
+
+out, cfg = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ours(name):
+    return any(ns in name for ns in ("ipf::", "ipm::", "ipk::"))
+
+
+def short(name):
+    return re.sub(r"^void ", "", name).split("(")[0]
+
+
+kern = collections.OrderedDict()
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if ours(r["Name"]):
+            kern[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])}
+for pas in ("fetch", "write", "sq1", "sq2"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(out, pas, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if ours(r["Kernel_Name"]):
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in acc.items():
+        d = kern.setdefault(k, {})
+        for c, v in cs.items():
+            d[c] = sum(v) / len(v)
+            d[c + "_n"] = len(v)
+bench = None
+for ln in open(os.path.join(out, "stats.log")):
+    if ln.startswith("{"):
+        bench = json.loads(ln)
+lib = os.path.join(ROOT, "image_processing_amd", "lib", "libimgproc_hip.so")
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
+print(json.dumps({"config": cfg, "lib_sha16": sha, "bench_line_under_rocprof": bench, "kernels": kern}, indent=1))
