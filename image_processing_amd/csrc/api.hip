@@ -782,8 +782,10 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
             HIPCHK(c, ipf::launch_fused(p.fused, s.d_raw, 0, rowb, w, h, 1, s.d_mask, s.d_mom, c->d_tables, st));
         } else if (path == 1) {
             // front kernel ([demosaic] [blur3] HSV [blur5] inRange -> bytes) + bit-plane back end (morph list, moments, mask)
-            HIPCHK(c, ipf::launch_fused(p.front, s.d_raw, 0, rowb, w, h, 1, s.d_thresh, nullptr, c->d_tables, st));
-            HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, s.d_mask, s.d_mom, w, h, nr, p.pipe.second_order, st));
+            // the inRange planes go from one kernel to the other as bits (1/8 B per px and range) when the width allows
+            uint32_t *bits = ipf::front_writes_bits(w) ? reinterpret_cast<uint32_t *>(s.d_thresh) : nullptr;
+            HIPCHK(c, ipf::launch_fused(p.front, s.d_raw, 0, rowb, w, h, 1, s.d_thresh, nullptr, c->d_tables, st, bits));
+            HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, s.d_mask, s.d_mom, w, h, nr, p.pipe.second_order, st, bits));
         } else {
             int rc2 = run_unfused(c, s, s.d_raw, rowb, w, h, s.d_mask, s.d_mom, nullptr, st);
             if (rc2) return rc2;
@@ -961,7 +963,8 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
                                     c->d_tables, c->stream));
         bt.launches = 1;
     } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks)) {
-        const size_t need = (size_t)n * nr * px;
+        const bool as_bits = ipf::front_writes_bits(w);
+        const size_t need = as_bits ? (size_t)n * nr * h * ipm::bit_words(w) * 4 : (size_t)n * nr * px;
         if (need > c->thresh_batch_bytes) {  // grown on demand, kept for the life of the context
             HIPCHK(c, hipStreamSynchronize(c->stream));  // the other ticket may still be using the old buffer
             if (c->d_thresh_batch) HIPCHK(c, hipFree(c->d_thresh_batch));
@@ -970,10 +973,11 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
             HIPCHK(c, hipMalloc((void **)&c->d_thresh_batch, need));
             c->thresh_batch_bytes = need;
         }
+        uint32_t *bits = as_bits ? reinterpret_cast<uint32_t *>(c->d_thresh_batch) : nullptr;
         HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, c->d_thresh_batch,
-                                    nullptr, c->d_tables, c->stream));
+                                    nullptr, c->d_tables, c->stream, bits));
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, c->d_thresh_batch, (u8 *)d_masks, bt.d_mom, w, h, n * nr,
-                                       p.pipe.second_order, c->stream));
+                                       p.pipe.second_order, c->stream, bits));
         bt.launches = 2;
     } else {
         for (int i = 0; i < n; i++) {
@@ -1050,19 +1054,22 @@ IMGPROC_API int imgproc_process_batch_device_noalloc(imgproc_ctx *c, const void 
     const bool front = !chain && p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks);
     if (!chain && !front)
         return fail(c, IMGPROC_EUNSUPPORTED, "no-allocation path: this pipeline / frame shape runs stage by stage (%dx%d)", w, h);
-    if (front && (size_t)n * nr * px > NA_PLANE_BYTES)
-        return fail(c, IMGPROC_ESIZE, "no-allocation path: %d frames x %d ranges x %dx%d inRange planes > %zu scratch bytes", n, nr,
-                    w, h, NA_PLANE_BYTES);
+    const bool as_bits = ipf::front_writes_bits(w);  // bit planes (1/8 B per px) unless w % 4 != 0
+    const size_t plane_bytes = as_bits ? (size_t)h * ipm::bit_words(w) * 4 : px;
+    if (front && (size_t)n * nr * plane_bytes > NA_PLANE_BYTES)
+        return fail(c, IMGPROC_ESIZE, "no-allocation path: %d frames x %d ranges x %dx%d inRange planes (%zu bytes each) > %zu scratch bytes",
+                    n, nr, w, h, plane_bytes, NA_PLANE_BYTES);
     // the array keeps the last call's contents: the sums must start at zero (the planes are fully rewritten)
     HIPCHK(c, hipMemsetAsync(d_mom, 0, mom_bytes, c->stream));
     if (chain) {
         HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks, d_mom,
                                     c->d_tables, c->stream));
     } else {
+        uint32_t *bits = as_bits ? reinterpret_cast<uint32_t *>(d_planes) : nullptr;
         HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, d_planes, nullptr,
-                                    c->d_tables, c->stream));
+                                    c->d_tables, c->stream, bits));
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, d_planes, (u8 *)d_masks, d_mom, w, h, n * nr, p.pipe.second_order,
-                                       c->stream));
+                                       c->stream, bits));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_na_mom, d_mom, mom_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

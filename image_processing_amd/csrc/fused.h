@@ -35,6 +35,9 @@ bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_
 // d_mom[n][n_ranges][6] (caller zeroes)
 hipError_t launch_fused(const FusedPlan &plan, const ipk::u8 *d_frames, size_t frame_stride, size_t row_stride, int w,
                         int h, int n, ipk::u8 *d_masks, unsigned long long *d_mom, const int *d_tables,
-                        hipStream_t stream);
+                        hipStream_t stream, uint32_t *d_bits = nullptr);
+// A front plan (plan_front) can hand its inRange result to the bit-plane back end as bits instead of bytes when the
+// strips' borders fall on byte borders of the bitmap: pass d_bits ([n][n_ranges][h][(w+31)/32] words) instead of d_masks.
+inline bool front_writes_bits(int w) { return (w & 3) == 0; }
 
 }  // namespace ipf

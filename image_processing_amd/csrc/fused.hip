@@ -1,6 +1,11 @@
 // Planning and launch of the fused chain kernel (fused_kernel.hpp); the instantiations live in fused_inst_*.hip.
 #include "fused_kernel.hpp"
 
+#include <array>
+#include <cmath>
+#include <map>
+#include <mutex>
+
 namespace ipf {
 
 // ---------------------------------------------------------------------------------------------
@@ -69,11 +74,38 @@ bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_
 
 static int g_seg_rows_override = -1;
 
+static hipError_t dispatch_variant(const FusedPlan &plan, const Variant &v, const Args &a, dim3 grid, hipStream_t stream)
+{
+    if (plan.bayer) return v.cap <= 2 ? launch_variant_bayer_small(v, a, grid, stream) : launch_variant_bayer_large(v, a, grid, stream);
+    return v.cap <= 2 ? launch_variant_plain_small(v, a, grid, stream) : launch_variant_plain_large(v, a, grid, stream);
+}
+
+// Wave slots of the current device for one instantiation (SIMDs x resident waves per SIMD), looked up once per
+// instantiation and device.  0 when the runtime cannot tell.
+static int wave_slots(const FusedPlan &plan, const Variant &v)
+{
+    static std::mutex mu;
+    static std::map<std::array<int, 9>, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const std::array<int, 9> key = {dev, plan.bayer, v.pre_k, v.post_k, v.rgb, v.cap, v.second_order, v.mode, 0};
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int cus = 0, occ = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    Variant q = v;
+    q.waves_per_simd = &occ;
+    (void)dispatch_variant(plan, q, Args{}, dim3(1), nullptr);
+    return cache[key] = cus * 4 * occ;
+}
+
 hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_stride, size_t row_stride, int w,
                         int h, int n, u8 *d_masks, unsigned long long *d_mom, const int *d_tables,
-                        hipStream_t stream)
+                        hipStream_t stream, uint32_t *d_bits)
 {
     if (n <= 0) return hipSuccess;
+    if (d_bits && (plan.mode != 1 || (w & 3))) return hipErrorInvalidValue;  // bit planes: front end only, strip borders on byte borders
     if (g_seg_rows_override < 0) {
         const char *e = getenv("IMGPROC_SEG_ROWS");
         g_seg_rows_override = e ? atoi(e) : 0;
@@ -83,6 +115,8 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     a.frame_stride = frame_stride;
     a.row_stride = row_stride;
     a.masks = d_masks;
+    a.bits = d_bits;
+    a.bit_words = (w + 31) / 32;
     a.mom = d_mom;
     a.tables = d_tables;
     a.w = w;
@@ -96,14 +130,40 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
         a.last_base = w - sv;
         a.split_x = std::min((a.n_strips - 1) * sv, (w - 16) & ~3);
     }
-    // 100 rows per wave: measured optimum at steady clocks (1920x1200 x 256: 0.77 ms against 0.79 at 200, 0.80 at 67; the
+    Variant v{};
+    v.pre_k = plan.pre_k;
+    v.post_k = plan.post_k;
+    v.rgb = plan.bidx == 2;
+    const int nr = plan.bounds.n;
+    v.cap = nr <= 2 ? nr : (nr <= 4 ? 4 : 8);
+    v.second_order = plan.second_order;
+    v.mode = d_bits ? 2 : plan.mode;
+    // ~100 rows per wave: measured optimum at steady clocks (1920x1200 x 256: 0.77 ms against 0.79 at 200, 0.80 at 67; the
     // fill / drain of a segment costs about as much as 9 rows, finer items even out the end of the launch)
     int target = g_seg_rows_override > 0 ? g_seg_rows_override : 100;
     if (g_seg_rows_override <= 0) {
-        // Small jobs (the live node: ONE frame per callback) are latency-bound: a 100-row segment is one wave's serial
-        // work.  Shorter segments (more look-ahead rows re-done, a few % more work) until the chip has ~6 waves per CU.
         const long long items100 = (long long)a.n_strips * ((h + 99) / 100) * n;
-        if (items100 < 1536) target = std::max(32, (int)((long long)h * a.n_strips * n / 1536));
+        if (items100 < 1536) {
+            // Small jobs (the live node: ONE frame per callback) are latency-bound: a 100-row segment is one wave's serial
+            // work.  Shorter segments (more look-ahead rows re-done, a few % more work) until the chip has ~6 waves per CU.
+            target = std::max(32, (int)((long long)h * a.n_strips * n / 1536));
+        } else {
+            // Large jobs: among segment heights of 90..130 rows take the one that leaves the last round of waves fullest
+            // (waves = a whole multiple of the instantiation's wave slots: 12 x 100 rows at 6 waves per SIMD for the chain
+            // kernel, 10 x 120 rows at 5 for the pre-blur front end on a 256-frame 1920x1200 batch; measured 2-4 %)
+            const int slots = wave_slots(plan, v);
+            if (slots > 0 && items100 >= slots) {
+                double best = 1e9;
+                for (int ns = (h + 129) / 130; ns <= (h + 89) / 90; ns++) {
+                    const int rows = (h + ns - 1) / ns;
+                    if (rows < 90 || rows > 130) continue;
+                    const double rounds = (double)a.n_strips * ns * n / slots;
+                    const double waste = std::ceil(rounds) - rounds;  // empty share of the last round
+                    const double score = waste / std::ceil(rounds) + 0.0005 * std::abs(rows - 100);
+                    if (score < best) best = score, target = rows;
+                }
+            }
+        }
     }
     a.n_segs = (h + target - 1) / target;
     a.seg_rows = (h + a.n_segs - 1) / a.n_segs;
@@ -114,7 +174,6 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
     a.total_items = a.n_strips * a.n_segs * n;
     a.op0 = plan.kind[0];
     a.op1 = plan.kind[1];
-    const int nr = plan.bounds.n;
     const int sh = plan.post_k == 5 ? 8 : 0;  // blurred fields are 8.8
     for (int r = 0; r < MAX_NR; r++) {  // ranges beyond nr (spare capacity of the 4 / 8 variants) never match
         a.hs_lo[r] = 0; a.hs_hi[r] = 0xFFFFFFFFu; a.v_lo[r] = 0xFFFFFFFFu; a.v_hi[r] = 0;
@@ -139,17 +198,9 @@ hipError_t launch_fused(const FusedPlan &plan, const u8 *d_frames, size_t frame_
             a.v_hi[r] = hi16(2) - lo16(2);
         }
     }
-    Variant v{};
-    v.pre_k = plan.pre_k;
-    v.post_k = plan.post_k;
-    v.rgb = plan.bidx == 2;
-    v.cap = nr <= 2 ? nr : (nr <= 4 ? 4 : 8);
-    v.second_order = plan.second_order;
-    v.mode = plan.mode;
     a.nr = nr;
     const dim3 grid((a.total_items + 3) / 4);
-    if (plan.bayer) return v.cap <= 2 ? launch_variant_bayer_small(v, a, grid, stream) : launch_variant_bayer_large(v, a, grid, stream);
-    return v.cap <= 2 ? launch_variant_plain_small(v, a, grid, stream) : launch_variant_plain_large(v, a, grid, stream);
+    return dispatch_variant(plan, v, a, grid, stream);
 }
 
 }  // namespace ipf

@@ -39,6 +39,8 @@ struct Args {
     const u8 *frames;
     size_t frame_stride, row_stride;
     u8 *masks;
+    uint32_t *bits;  // MODE 2: inRange result as bit planes [n][nr][h][bit_words], bit i of word j = pixel 32 j + i
+    int bit_words;
     unsigned long long *mom;
     const int *tables;
     int w, h, n;
@@ -398,8 +400,34 @@ __device__ __forceinline__ void store_part(u8 *px, uint32_t bytes, uint32_t own)
         if (own & (1u << k)) px[k] = (u8)(bytes >> (8 * k));
 }
 
+// 8x8 nibble transpose across the 8 lanes of a group (lane j's nibble n <-> lane n's nibble j): three butterfly stages,
+// the partner's value through ds_swizzle (LDS crossbar, no VALU), the merge one v_perm / v_bfi with per-lane constants.
+struct TransposeConsts {
+    uint32_t sel4, sel2, m1, rot1;
+};
+__device__ __forceinline__ TransposeConsts transpose_consts(int lane)
+{
+    TransposeConsts c;
+    c.sel4 = (lane & 4) ? 0x03020706u : 0x05040100u;  // v_perm_b32(partner, own, sel): bytes 0-3 = own, 4-7 = partner
+    c.sel2 = (lane & 2) ? 0x03070105u : 0x06020400u;
+    c.m1 = (lane & 1) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;    // nibbles this lane keeps in the last stage
+    c.rot1 = (lane & 1) ? 4u : 28u;                    // partner rotated right by this: >> 4 (odd lanes), << 4 (even lanes)
+    return c;
+}
+__device__ __forceinline__ uint32_t transpose_nibbles8(uint32_t v, const TransposeConsts &c)
+{
+    uint32_t q = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);  // lane ^ 4
+    v = __builtin_amdgcn_perm(q, v, c.sel4);
+    q = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x081F);  // lane ^ 2
+    v = __builtin_amdgcn_perm(q, v, c.sel2);
+    q = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x041F);  // lane ^ 1
+    return (v & c.m1) | (alignbit(q, q, (int)c.rot1) & ~c.m1);
+}
+
 // MODE 0: whole chain (up to two 3x3 ops, moments, final mask).  MODE 1: front end only: the inRange output is
 // written as 0/255 bytes to a.masks (the bit-plane back end, morphbits.hip, runs the morph list and the moments).
+// MODE 2: the same front end, but the inRange output goes out as bit planes (a.bits, 1/8 B per px and range): the
+// kernel holds it as bits anyway, and the back end wants bits (w % 4 == 0 only: strip borders are byte borders then).
 // BAYER: the frames are BayerRG8 mosaics (1 B/px); every fed row loads the three mosaic rows it is interpolated from.
 template <int PRE_K, int POST_K, bool RGB, int NR, int PF, bool M2, int MODE, bool BAYER>
 __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
@@ -510,6 +538,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
         convert((S0 + q) & 7, q >= (PRE_K == 3 ? 2 : 0), q);
     }
 
+    const TransposeConsts tc = transpose_consts(lane);  // MODE 2 only
     uint32_t acc[NR], prev1[NR], prev2[NR];
     uint32_t m00[NR], m10[NR], m01[NR];
     unsigned long long m20[NR], m11[NR], m02[NR];  // second-order sums (only with M2)
@@ -588,6 +617,31 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
             }
         }
         const int yt = t0 + b * 8;  // image row of tile position 0 at the inRange stage
+        if (MODE == 2) {
+            // ---- front end, bits out.  Plain input (one halo lane): lane l <- lane l+1, so that lane l stands for columns
+            // base + 4l and every second lane starts a byte of the bitmap (Bayer, two halo lanes: base - 8 + 4l already
+            // does).  Then the 8 lanes of a group trade nibbles so that lane i holds the 32-px word of tile row 7 - i. ----
+            const int li = lane & 7, xg = base - (BAYER ? 8 : 0) + 32 * (lane >> 3);
+            const int y = yt + 7 - li;
+            const int fb = max(0, (own_lo - xg) >> 3), lb = min(4, (own_hi - xg + 7) >> 3);  // bytes [fb, lb) of the word are this strip's
+            const bool store = y >= ys && y < ye && lb > fb;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
+                const uint32_t word = transpose_nibbles8(BAYER ? acc[r] : from_right(acc[r]), tc);
+                if (store) {
+                    u8 *dst = reinterpret_cast<u8 *>(a.bits + (((size_t)frame * a.nr + r) * h + y) * a.bit_words) + (xg >> 3);
+                    if (fb == 0 && lb == 4) {
+                        *reinterpret_cast<uint32_t *>(dst) = word;  // byte-aligned, not always dword-aligned: fine on gfx950
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (k >= fb && k < lb) dst[k] = (u8)(word >> (8 * k));
+                    }
+                }
+            }
+            continue;
+        }
         if (MODE == 1) {
             // ---- front end only: the inRange rows go out as 0/255 bytes ----
 #pragma unroll
@@ -673,7 +727,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
         }
     }
 
-    if (MODE == 1) return;
+    if (MODE != 0) return;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
         if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
@@ -719,6 +773,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 
 struct Variant {
     int pre_k, post_k, rgb, cap, second_order, mode;
+    int *waves_per_simd;  // non-null: do not launch, report how many waves of this instantiation fit one SIMD
 };
 hipError_t launch_variant_plain_small(const Variant &v, const Args &a, dim3 grid, hipStream_t stream);
 hipError_t launch_variant_plain_large(const Variant &v, const Args &a, dim3 grid, hipStream_t stream);
@@ -733,12 +788,19 @@ hipError_t launch_variant_bayer_large(const Variant &v, const Args &a, dim3 grid
         auto go = [&](auto pre, auto post, auto rgb, auto cap) {                                                        \
             constexpr int PRE = decltype(pre)::value, POST = decltype(post)::value, CAP = decltype(cap)::value;         \
             constexpr bool RGBV = decltype(rgb)::value;                                                                 \
-            if (v.mode == 1)                                                                                            \
-                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, false, 1, BAYERV>), grid, block, 0, stream, a); \
-            else if (v.second_order)                                                                                    \
-                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, true, 0, BAYERV>), grid, block, 0, stream, a);  \
-            else                                                                                                        \
-                hipLaunchKernelGGL((k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, false, 0, BAYERV>), grid, block, 0, stream, a); \
+            auto run = [&](auto kernel) {                                                                               \
+                if (v.waves_per_simd) {                                                                                 \
+                    int nb = 0; /* 256-thread blocks per CU == waves per SIMD */                                        \
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess) nb = 0;        \
+                    *v.waves_per_simd = nb;                                                                             \
+                } else {                                                                                                \
+                    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);                                              \
+                }                                                                                                       \
+            };                                                                                                          \
+            if (v.mode == 2) run(k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, false, 2, BAYERV>);                        \
+            else if (v.mode == 1) run(k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, false, 1, BAYERV>);                   \
+            else if (v.second_order) run(k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, true, 0, BAYERV>);                 \
+            else run(k_fused_chain<PRE, POST, RGBV, CAP, IPF_PF, false, 0, BAYERV>);                                    \
         };                                                                                                              \
         using std::integral_constant;                                                                                   \
         auto with_cap = [&](auto pre, auto post, auto rgb) {                                                            \

@@ -31,8 +31,12 @@ struct Plan {
 // false when the list cannot run on bit planes (an element row that is not one contiguous span, reach too large)
 bool plan_bitmorph(const imgproc_pipeline &pipe, const ipk::Element *elems, Plan *out);
 
-// d_thresh / d_masks: [planes][h][w] bytes (d_masks may be null: moments only); moments added into d_mom[planes][6]
+// d_thresh / d_masks: [planes][h][w] bytes (d_masks may be null: moments only); moments added into d_mom[planes][6].
+// d_tbits != null: the inRange planes come as bits instead, [planes][h][bit_words(w)] words, bit i of word j = pixel
+// 32 j + i (what the front kernel and the inRange kernel write for this back end); d_thresh is then ignored.
+inline int bit_words(int w) { return (w + 31) / 32; }
 hipError_t launch_bitmorph(const Plan &plan, const Group *d_groups, const ipk::u8 *d_thresh, ipk::u8 *d_masks,
-                           unsigned long long *d_mom, int w, int h, int planes, int second_order, hipStream_t stream);
+                           unsigned long long *d_mom, int w, int h, int planes, int second_order, hipStream_t stream,
+                           const uint32_t *d_tbits = nullptr);
 
 }  // namespace ipm

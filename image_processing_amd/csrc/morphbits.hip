@@ -25,7 +25,9 @@ constexpr int LS_MAX = LW_MAX + 1;  // row stride in LDS: the data words + one p
 constexpr int LH_MAX = TH + MAX_HALO_ROWS;
 
 struct Args {
-    const u8 *thresh;  // [planes][h][w]
+    const u8 *thresh;  // [planes][h][w] 0/255 bytes, or null when the input comes as bit planes:
+    const uint32_t *tbits;  // [planes][h][twords] words, bit i of word j = pixel 32 j + i (bits beyond w are ignored)
+    int twords;
     u8 *masks;         // [planes][h][w]
     unsigned long long *mom;  // [planes][6], added into
     const Group *groups;
@@ -43,6 +45,18 @@ static_assert(WORDS_PER_THREAD == 13, "the vertical pass is instantiated for 1..
 constexpr int CH = 4;  // words a thread carries through one horizontal window pass at a time
 
 __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, int s) { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s); }
+
+// out-of-image masks of one tile word (the pack phase runs before the shared copies of them are visible)
+__device__ __forceinline__ uint32_t s_rinv_early(int y, int h) { return (y >= 0 && y < h) ? 0u : 0xFFFFFFFFu; }
+__device__ __forceinline__ uint32_t cinv_word(int x_org, int k, int LW, int w)
+{
+    const int x0 = x_org + k * 32;
+    if (k >= LW || x0 >= w || x0 + 32 <= 0) return 0xFFFFFFFFu;
+    uint32_t inv = 0;
+    if (x0 < 0) inv |= (1u << (-x0)) - 1u;
+    if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);
+    return inv;
+}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_bitmorph(const Args a)
 {
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint32_t rcp = (65536u + LS - 1) / LS;  // idx / LS == (idx * rcp) >> 16 for idx < 3400 (LS <= 21)
     const int x_org = (tx * tww - a.hwl) * 32;  // pixel x of tile word 0
     const int y_org = ty * th - a.ht;
-    const u8 *src = a.thresh + (size_t)plane * w * h;
+    const u8 *src = a.thresh ? a.thresh + (size_t)plane * w * h : nullptr;
     const bool vec = true;  // dword accesses may be unaligned (w % 4 != 0): fine for gfx950 global memory (scripts/ubench/unaligned.hip)
     auto mask_of = [](int kind) { return kind ? 0xFFFFFFFFu : 0u; };  // dilate(X) = ~erode(~X)
     uint32_t *const cur = s_buf + 1, *const alt = s_buf + N_WORDS_MAX + 2;
@@ -86,49 +100,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     // ---- pack: one 32-px word per thread-iteration, stored in the first group's erode domain ----
     const uint32_t km_first = mask_of(a.groups[0].kind);
-    // PB words per thread at a time: all their global loads are issued before the first is used, so a thread waits for
-    // HBM two or three times per tile instead of once per word
-    constexpr int PB = 5;
-    for (int base = 0; base < LH * LS; base += 256 * PB) {
-        uint32_t v[PB][8];
-        int px0[PB], py[PB];
+    if (a.tbits) {
+        // ---- bit planes in (the front kernel / the inRange kernel already hold their result as bits): one aligned
+        // word load per tile word; out-of-image bits are forced neutral by the row / column masks ----
+        const uint32_t *bsrc = a.tbits + (size_t)plane * h * a.twords;
+        const int j_org = tx * tww - a.hwl;  // image word index of tile word 0
+        constexpr int PBB = 8;
+        for (int base = 0; base < LH * LS; base += 256 * PBB) {
+            uint32_t v[PBB];
 #pragma unroll
-        for (int j = 0; j < PB; j++) {
-            const int idx = base + tid + 256 * j;
-            const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
-            const int y = y_org + r, x0 = k == LW ? w : x_org + k * 32;  // the pad word: "outside" -> all-ones
-            px0[j] = x0;
-            py[j] = (idx < LH * LS && y >= 0 && y < h) ? y : -1;
-            const bool fast = vec && py[j] >= 0 && x0 >= 0 && x0 + 32 <= w;
-            // unconditional loads (words that take no fast path read the group list instead: always 32 readable bytes)
-            const uint32_t *p = fast ? reinterpret_cast<const uint32_t *>(src + (size_t)y * w + x0)
-                                     : reinterpret_cast<const uint32_t *>(a.groups);
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[j][q] = p[q];
-        }
-#pragma unroll
-        for (int j = 0; j < PB; j++) {
-            const int idx = base + tid + 256 * j;
-            const int y = py[j], x0 = px0[j];
-            uint32_t bits = 0, inv = 0xFFFFFFFFu;
-            if (y >= 0 && x0 < w && x0 + 32 > 0) {
-                inv = 0;
-                if (vec && x0 >= 0 && x0 + 32 <= w) {
-                    // 0/255 bytes -> bits: two dwords (8 px) per byte of the word, one 4x8-bit dot product each
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t hi4 = __builtin_amdgcn_udot4(v[j][2 * q + 1] & 0x01010101u, 0x80402010u, 0u, false);
-                        bits |= __builtin_amdgcn_udot4(v[j][2 * q] & 0x01010101u, 0x08040201u, hi4, false) << (8 * q);
-                    }
-                } else {  // a word that the image's left / right edge cuts
-                    if (x0 < 0) inv |= (1u << (-x0)) - 1u;
-                    if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);
-                    const u8 *row = src + (size_t)y * w;
-                    for (int i = 0; i < 32; i++)
-                        if (x0 + i >= 0 && x0 + i < w && row[x0 + i]) bits |= 1u << i;
-                }
+            for (int j = 0; j < PBB; j++) {
+                const int idx = base + tid + 256 * j;
+                const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
+                const int y = y_org + r, jw = j_org + k;
+                const bool in = idx < LH * LS && k < LW && y >= 0 && y < h && jw >= 0 && jw < a.twords;
+                v[j] = in ? bsrc[(size_t)y * a.twords + jw] : 0u;
             }
-            if (idx < LH * LS) cur[idx] = (bits ^ km_first) | inv;
+#pragma unroll
+            for (int j = 0; j < PBB; j++) {
+                const int idx = base + tid + 256 * j;
+                const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
+                if (idx < LH * LS) cur[idx] = (v[j] ^ km_first) | s_rinv_early(y_org + r, h) | cinv_word(x_org, k, LW, w);
+            }
+        }
+    } else {
+        // PB words per thread at a time: all their global loads are issued before the first is used, so a thread waits for
+        // HBM two or three times per tile instead of once per word
+        constexpr int PB = 5;
+        for (int base = 0; base < LH * LS; base += 256 * PB) {
+            uint32_t v[PB][8];
+            int px0[PB], py[PB];
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                const int idx = base + tid + 256 * j;
+                const int r = (int)(((uint32_t)idx * rcp) >> 16), k = idx - r * LS;
+                const int y = y_org + r, x0 = k == LW ? w : x_org + k * 32;  // the pad word: "outside" -> all-ones
+                px0[j] = x0;
+                py[j] = (idx < LH * LS && y >= 0 && y < h) ? y : -1;
+                const bool fast = vec && py[j] >= 0 && x0 >= 0 && x0 + 32 <= w;
+                // unconditional loads (words that take no fast path read the group list instead: always 32 readable bytes)
+                const uint32_t *p = fast ? reinterpret_cast<const uint32_t *>(src + (size_t)y * w + x0)
+                                         : reinterpret_cast<const uint32_t *>(a.groups);
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[j][q] = p[q];
+            }
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                const int idx = base + tid + 256 * j;
+                const int y = py[j], x0 = px0[j];
+                uint32_t bits = 0, inv = 0xFFFFFFFFu;
+                if (y >= 0 && x0 < w && x0 + 32 > 0) {
+                    inv = 0;
+                    if (vec && x0 >= 0 && x0 + 32 <= w) {
+                        // 0/255 bytes -> bits: two dwords (8 px) per byte of the word, one 4x8-bit dot product each
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t hi4 = __builtin_amdgcn_udot4(v[j][2 * q + 1] & 0x01010101u, 0x80402010u, 0u, false);
+                            bits |= __builtin_amdgcn_udot4(v[j][2 * q] & 0x01010101u, 0x08040201u, hi4, false) << (8 * q);
+                        }
+                    } else {  // a word that the image's left / right edge cuts
+                        if (x0 < 0) inv |= (1u << (-x0)) - 1u;
+                        if (x0 + 32 > w) inv |= ~((1u << (w - x0)) - 1u);
+                        const u8 *row = src + (size_t)y * w;
+                        for (int i = 0; i < 32; i++)
+                            if (x0 + i >= 0 && x0 + i < w && row[x0 + i]) bits |= 1u << i;
+                    }
+                }
+                if (idx < LH * LS) cur[idx] = (bits ^ km_first) | inv;
+            }
         }
     }
     __syncthreads();
@@ -427,12 +466,15 @@ bool plan_bitmorph(const imgproc_pipeline &pipe, const ipk::Element *elems, Plan
 }
 
 hipError_t launch_bitmorph(const Plan &plan, const Group *d_groups, const u8 *d_thresh, u8 *d_masks,
-                           unsigned long long *d_mom, int w, int h, int planes, int second_order, hipStream_t stream)
+                           unsigned long long *d_mom, int w, int h, int planes, int second_order, hipStream_t stream,
+                           const uint32_t *d_tbits)
 {
     if (planes <= 0 || w <= 0 || h <= 0) return hipSuccess;
     if (w >= (1 << 24) || h >= (1 << 24)) return hipErrorInvalidValue;  // 24-bit multiplies in the moment sums
     Args a{};
-    a.thresh = d_thresh;
+    a.thresh = d_tbits ? nullptr : d_thresh;
+    a.tbits = d_tbits;
+    a.twords = (w + 31) / 32;
     a.masks = d_masks;
     a.mom = d_mom;
     a.groups = d_groups;

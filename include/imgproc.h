@@ -165,8 +165,9 @@ int imgproc_batch_wait(imgproc_ctx *ctx, int ticket, imgproc_result *out);
  * as imgproc_process_batch_device, but the library's scratch (the moment sums; the inRange planes between the
  * front kernel and the bit-plane kernel) lives in a static per-GPU device array of 32 MiB + 384 KiB instead of
  * allocated buffers, and the call makes no hipMalloc / hipFree / hipHostMalloc.  Limits: n <= max_batch,
- * n * n_ranges <= 8192, and for pipelines that run as front kernel + bit-plane morphology
- * n * n_ranges * w * h <= 32 MiB (IMGPROC_ESIZE beyond); pipelines or frame shapes that run stage by stage
+ * n * n_ranges <= 8192, and for pipelines that run as front kernel + bit-plane morphology the inRange planes
+ * (n * n_ranges * h * 4 * ceil(w / 32) bytes as bit planes; n * n_ranges * w * h when w % 4 != 0) <= 32 MiB
+ * (IMGPROC_ESIZE beyond); pipelines or frame shapes that run stage by stage
  * return IMGPROC_EUNSUPPORTED.  Synchronous (returns with `out` filled).  Every call on a GPU shares that GPU's
  * array: calls that overlap on one GPU (two contexts, two threads) race. */
 int imgproc_process_batch_device_noalloc(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride,

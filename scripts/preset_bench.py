@@ -16,11 +16,11 @@ P = {"pose_estimate": dict(), "pose_estimate_full": dict(post_blur_k=5, morph=ip
      "polygon_path": dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH),
      "baseline_8r": dict(post_blur_k=5, morph=ip.MORPH_BASELINE)}  # eight hue bands in one launch (capacity-8 variant)
 R8 = [((20 * i, 60, 60), (20 * i + 19, 256, 256)) for i in range(8)]
-w, h, n = 1920, 1200, 64
+w, h, n = 1920, 1200, int(os.environ.get("PRESET_BATCH", "64"))
 frames = synth_batch(w, h, n, unique=4)
 with ip.ImgProc(w, h, n_slots=1, max_batch=n) as g:
     d_in = g.dev_alloc(frames.nbytes)
-    d_out = g.dev_alloc(8 * n * w * h)
+    d_out = g.dev_alloc((8 if any(a.endswith("_8r") for a in (sys.argv[1:] or list(P))) else 1) * n * w * h)
     g.dev_upload(d_in, frames)
     raw = (L.Result * n)()
     for name in (sys.argv[1:] or list(P)):

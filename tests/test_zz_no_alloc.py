@@ -34,7 +34,7 @@ def test_noalloc_matches_process_batch_device(preset):
         g.set_ranges(RANGES)
         assert not g.plan.startswith("stage kernels")
         # two calls in a row on the same GPU's scratch, the second with a smaller input (fewer, smaller frames)
-        for (w, h, n, seed) in ((640, 480, 6, 5), (250, 131, 3, 6)):
+        for (w, h, n, seed) in ((640, 480, 6, 5), (250, 131, 3, 6), (252, 131, 2, 7)):
             frames = synth_batch(w, h, n, seed=seed)
             d_in = g.dev_alloc(frames.nbytes)
             d_ref, d_out = g.dev_alloc(n * 2 * w * h), g.dev_alloc(n * 2 * w * h)
@@ -58,10 +58,15 @@ def test_noalloc_limits():
         w, h, n = 1920, 1200, 16
         d_in = g.dev_alloc(n * w * h * 3)
         try:
-            g.set_ranges([DEFAULT_RANGE])
-            g.set_pipeline(**PRESETS["polygon_path"])  # 16 planes of 1920x1200 > 32 MiB of scratch
+            g.set_pipeline(**PRESETS["polygon_path"])
+            g.set_ranges([DEFAULT_RANGE] * 8)  # 128 inRange bit planes of 1920x1200 (288 000 B each) > 32 MiB of scratch
             rc, _ = noalloc(g, d_in, w, h, n, None)
             assert rc == L.ESIZE and b"scratch" in g.lib.imgproc_last_error(g._ctx)
+            g.set_ranges([DEFAULT_RANGE])
+            rc, _ = noalloc(g, d_in, w - 2, h, n, None)  # w % 4 != 0: byte planes, 16 x 2.3 MB > 32 MiB
+            assert rc == L.ESIZE and b"scratch" in g.lib.imgproc_last_error(g._ctx)
+            rc, res = noalloc(g, d_in, w, h, n, None)  # 16 bit planes fit
+            assert rc == 0 and res[15].n_ranges == 1
             rc, _ = noalloc(g, d_in, w, h, 17, None)
             assert rc == L.ESIZE
             g.set_pipeline(post_blur_k=15, morph=ip.MORPH_BASELINE)  # stage-by-stage pipeline
