@@ -427,11 +427,20 @@ int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, i
     s.blur_ptr = blur;
     if (upto == IMGPROC_STAGE_BLUR) return 0;
     const int nr = p.bounds.n;
+    const bool to_bitmorph = p.bm_ok && !p.pipe.force_unfused;
+    if (to_bitmorph && upto > IMGPROC_STAGE_THRESH && !p.pipe.keep_stages) {
+        // nobody asked for the inRange bytes: the planes go to the bit-plane morphology as bits (1/8 B per px and range),
+        // then the whole morph list + moments + final masks for all ranges in one launch
+        uint32_t *bits = reinterpret_cast<uint32_t *>(s.d_thresh);
+        HIPCHK(c, ipk::launch_in_range_bits(blur, t3, bits, w, h, p.bounds, st));
+        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, nullptr, d_masks_out, d_mom, w, h, nr, p.pipe.second_order, st, bits));
+        if (launches) *launches += nl + 2;
+        return 0;
+    }
     HIPCHK(c, ipk::launch_in_range(blur, t3, s.d_thresh, (size_t)w, px, w, h, p.bounds, st));
     nl++;
     if (upto == IMGPROC_STAGE_THRESH) return 0;
-    if (p.bm_ok && !p.pipe.force_unfused) {
-        // whole morph list + moments + final masks for all ranges in one launch on bit planes
+    if (to_bitmorph) {
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, s.d_thresh, d_masks_out, d_mom, w, h, nr, p.pipe.second_order, st));
         nl++;
     } else {
@@ -834,7 +843,10 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     s.frame_epoch = c->plan_epoch;
     s.nr = p.bounds.n;
     s.second = p.pipe.second_order != 0;
-    s.valid_upto = path == 2 ? IMGPROC_STAGE_THRESH : -1;  // the fast paths leave no colour stage behind
+    // the fast paths leave no colour stage behind; the stage path leaves them all, except that its inRange planes are
+    // bits, not bytes, when they went straight to the bit-plane morphology
+    const bool thresh_as_bits = p.bm_ok && !p.pipe.force_unfused && !p.pipe.keep_stages;
+    s.valid_upto = path == 2 ? (thresh_as_bits ? IMGPROC_STAGE_BLUR : IMGPROC_STAGE_THRESH) : -1;
     s.masked_range = (path == 2 && p.pipe.keep_stages) ? 0 : -1;
     return IMGPROC_OK;
 }

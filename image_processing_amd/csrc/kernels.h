@@ -38,6 +38,9 @@ hipError_t launch_gaussian_strip(const u8 *src, size_t sstride, u8 *dst, size_t 
 // dst plane r at dst + r*plane_stride
 hipError_t launch_in_range(const u8 *src, size_t sstride, u8 *dst, size_t dstride, size_t plane_stride, int w,
                            int h, const Bounds &b, hipStream_t stream);
+// inRange for 1..8 ranges with bit planes out: dst[range][h][(w+31)/32] words, bit i of word j = pixel 32 j + i
+hipError_t launch_in_range_bits(const u8 *src, size_t sstride, uint32_t *dst, int w, int h, const Bounds &b,
+                                hipStream_t stream);
 hipError_t launch_morph(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int kind,
                         const Element &e, hipStream_t stream);
 // adds into d_m[6] (u64: m00 m10 m01 m20 m11 m02); caller zeroes

@@ -238,6 +238,83 @@ __global__ __launch_bounds__(256) void k_in_range(const u8 *__restrict__ src, si
     }
 }
 
+// The same test with the result as bit planes (what the bit-plane morphology wants, morphbits.hip): 32 pixels per lane,
+// plane r's word j = bit i set iff pixel 32 j + i lies in range r.  1/8 B per pixel and range instead of 1 B.
+__global__ __launch_bounds__(256) void k_in_range_bits(const u8 *__restrict__ src, size_t sstride, uint32_t *__restrict__ dst,
+                                                       int words, int w, int h, Bounds b, int align)
+{
+    __shared__ u8 s_t[3][256];
+    {
+        const int v = threadIdx.y * 64 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            unsigned m = 0;
+            for (int r = 0; r < b.n; r++) m |= (v >= b.lo[r][c] && v <= b.hi[r][c]) ? (1u << r) : 0u;
+            s_t[c][v] = (u8)m;
+        }
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 64 + threadIdx.x;  // word index in the row
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= h || j >= words) return;
+    const int x0 = j * 32, n = min(32, w - x0);
+    const u8 *s = src + (size_t)y * sstride + (size_t)x0 * 3;
+    uint32_t raw[24];
+    if (align == 16 && n == 32) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(s);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const uint4 q = p[i];
+            raw[4 * i] = q.x; raw[4 * i + 1] = q.y; raw[4 * i + 2] = q.z; raw[4 * i + 3] = q.w;
+        }
+    } else if (align >= 4 && n == 32) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(s);
+#pragma unroll
+        for (int i = 0; i < 24; i++) raw[i] = p[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            uint32_t v = 0;
+            for (int q = 0; q < 4; q++)
+                if ((4 * i + q) < 3 * n) v |= (uint32_t)s[4 * i + q] << (8 * q);
+            raw[i] = v;
+        }
+    }
+    uint32_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 8; g++) {  // 4 pixels = 3 dwords at a time
+        uint32_t m4 = 0;           // byte k = range set of pixel 4 g + k
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t m = 0xFFu;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int bi = 12 * g + 3 * k + c;
+                m &= s_t[c][(raw[bi >> 2] >> (8 * (bi & 3))) & 255u];
+            }
+            m4 |= m << (8 * k);
+        }
+        // bit r of the four bytes -> four consecutive bits of plane r's word (one 4 x 8-bit dot product per range)
+        for (int r = 0; r < b.n; r++) {
+            const uint32_t t = (m4 >> r) & 0x01010101u;
+            out[r] |= __builtin_amdgcn_udot4(t, 0x08040201u, 0u, false) << (4 * g);
+        }
+    }
+    // pixels beyond w (n < 32) matched the tables on zero bytes: clear them, the consumer ignores them anyway
+    const uint32_t keep = n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    for (int r = 0; r < b.n; r++) dst[((size_t)r * h + y) * words + j] = out[r] & keep;
+}
+
+hipError_t launch_in_range_bits(const u8 *src, size_t sstride, uint32_t *dst, int w, int h, const Bounds &b, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return hipSuccess;
+    const int words = (w + 31) / 32;
+    const int align = ((uintptr_t)src % 16 == 0 && sstride % 16 == 0) ? 16 : ((uintptr_t)src % 4 == 0 && sstride % 4 == 0) ? 4 : 1;
+    dim3 block(64, 4), grid((words + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_in_range_bits, grid, block, 0, stream, src, sstride, dst, words, w, h, b, align);
+    return hipGetLastError();
+}
+
 hipError_t launch_in_range(const u8 *src, size_t sstride, u8 *dst, size_t dstride, size_t plane_stride, int w,
                            int h, const Bounds &b, hipStream_t stream)
 {
