@@ -55,6 +55,7 @@ _SIGS = {
     "imgproc_set_pipeline": (C.c_int, [C.c_void_p, C.POINTER(Pipeline)]),
     "imgproc_set_ranges": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(I3), C.POINTER(I3)]),
     "imgproc_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
+    "imgproc_submit_pinned": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "imgproc_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Result)]),
     "imgproc_fetch_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "imgproc_process_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
@@ -83,6 +84,8 @@ _SIGS = {
     "imgproc_gaussian_taps": (C.c_int, [C.c_int, C.POINTER(C.c_int32)]),
     "imgproc_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "imgproc_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "imgproc_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "imgproc_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "imgproc_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "imgproc_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "imgproc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -721,7 +721,21 @@ IMGPROC_API int imgproc_pipeline_plan(const imgproc_ctx *c, char *buf, size_t le
 // ================================================================================================
 // streaming path
 // ================================================================================================
+static int submit_impl(imgproc_ctx *c, int slot, const uint8_t *data, size_t stride, int w, int h, bool zero_copy);
+
 IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, size_t stride, int w, int h)
+{
+    return submit_impl(c, slot, data, stride, w, h, false);
+}
+
+// The same without the staging copy: the DMA engine reads the caller's buffer, which must be page-locked
+// (imgproc_host_alloc, hipHostMalloc, hipHostRegister) and stay untouched until imgproc_wait returns for the slot.
+IMGPROC_API int imgproc_submit_pinned(imgproc_ctx *c, int slot, const uint8_t *data, size_t stride, int w, int h)
+{
+    return submit_impl(c, slot, data, stride, w, h, true);
+}
+
+static int submit_impl(imgproc_ctx *c, int slot, const uint8_t *data, size_t stride, int w, int h, bool zero_copy)
 {
     if (!c || !data) return IMGPROC_EINVAL;
     if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, IMGPROC_EINVAL, "slot %d", slot);
@@ -738,7 +752,7 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     // Staging: the caller's frame goes into the slot's pinned buffer (so msg->data may be released on return) and from
     // there to HBM.  Large frames go in row chunks, each chunk's DMA starting while the CPU copies the next one; with a
     // captured graph (IMGPROC_GRAPH) the whole-frame H2D is part of the graph instead.
-    const bool graph_path = c->graph_mode != 0;
+    const bool graph_path = c->graph_mode != 0 && !zero_copy;  // the captured graph uploads from the slot's staging buffer
     const bool big = rowb * h >= (1u << 20);
     // The helper threads raise throughput (4.1 k -> 6.9 k frames/s at 1920x1200 with three slots) but not the latency of
     // a lone frame (0.26 ms against 0.24 ms: waking them costs more than the single-threaded copy/DMA pipeline loses), so
@@ -768,7 +782,13 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
         e_up = hipMemcpyAsync(s.d_raw + (size_t)y0 * rowb, s.h_in + (size_t)y0 * rowb, rowb * (size_t)(y1 - y0),
                               hipMemcpyHostToDevice, s.stream);
     };
-    if (pooled) {
+    if (zero_copy) {
+        // straight from the caller's page-locked frame: one DMA (two-dimensional when its rows are padded), no CPU copy
+        if (stride == rowb)
+            e_up = hipMemcpyAsync(s.d_raw, data, rowb * (size_t)h, hipMemcpyHostToDevice, s.stream);
+        else
+            e_up = hipMemcpy2DAsync(s.d_raw, rowb, data, stride, rowb, (size_t)h, hipMemcpyHostToDevice, s.stream);
+    } else if (pooled) {
         c->copy_pool->stage(fr, issue);
     } else {
         for (int ci = 0; ci < fr.n_chunks; ci++) {
@@ -808,7 +828,7 @@ IMGPROC_API int imgproc_submit(imgproc_ctx *c, int slot, const uint8_t *data, si
     // direct launches both for the fused chain (3.8 k vs 4.3 k frames/s) and for polygon_path's 23-launch chain (2.2 k vs
     // 3.1 k frames/s), so direct launches are the default and the graph path stays selectable.
     const bool fused_now = path == 0;
-    if (c->graph_mode == 1 || (c->graph_mode == 2 && !fused_now)) {
+    if (!zero_copy && (c->graph_mode == 1 || (c->graph_mode == 2 && !fused_now))) {
         if (!s.graph_exec || s.graph_w != w || s.graph_h != h || s.graph_epoch != c->plan_epoch) {
             if (s.graph_exec) {
                 (void)hipGraphExecDestroy(s.graph_exec);
@@ -1282,6 +1302,21 @@ IMGPROC_API int imgproc_dev_free(imgproc_ctx *c, void *dptr)
     if (!c) return IMGPROC_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipFree(dptr));
+    return IMGPROC_OK;
+}
+// page-locked host memory for imgproc_submit_pinned (callers without their own HIP allocator)
+IMGPROC_API int imgproc_host_alloc(imgproc_ctx *c, size_t bytes, void **hptr)
+{
+    if (!c || !hptr) return IMGPROC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return IMGPROC_OK;
+}
+IMGPROC_API int imgproc_host_free(imgproc_ctx *c, void *hptr)
+{
+    if (!c) return IMGPROC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipHostFree(hptr));
     return IMGPROC_OK;
 }
 IMGPROC_API int imgproc_dev_upload(imgproc_ctx *c, void *dptr, const void *src, size_t bytes)

@@ -131,6 +131,31 @@ class ImgProc:
         self._chk(self.lib.imgproc_submit(self._ctx, slot, frame.ctypes.data, frame.strides[0], w, h), "imgproc_submit")
         self._slot_dims[slot] = (h, w)
 
+    def submit_pinned(self, slot: int, frame: np.ndarray):
+        """frame: a uint8 view of page-locked memory (host_alloc); it must stay untouched until wait(slot)."""
+        if frame.dtype != np.uint8 or frame.strides[-1] != 1 or (frame.ndim == 3 and frame.strides[1] != 3):
+            raise ImgProcError(L.EINVAL, "submit_pinned", "frame must be a uint8 array with packed pixels")
+        h, w = frame.shape[:2]
+        self._chk(self.lib.imgproc_submit_pinned(self._ctx, slot, frame.ctypes.data, frame.strides[0], w, h),
+                  "imgproc_submit_pinned")
+        self._slot_dims[slot] = (h, w)
+
+    def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
+        """A numpy array over page-locked host memory; release with host_free(arr)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self.lib.imgproc_host_alloc(self._ctx, max(n, 1), C.byref(p)), "imgproc_host_alloc")
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._chk(self.lib.imgproc_host_free(self._ctx, p), "imgproc_host_free")
+
     def wait(self, slot: int):
         r = L.Result()
         self._chk(self.lib.imgproc_wait(self._ctx, slot, C.byref(r)), "imgproc_wait")

@@ -141,6 +141,11 @@ int imgproc_set_ranges(imgproc_ctx *ctx, int n, const int32_t (*lo)[3], const in
  * uploads on the slot's own stream and enqueues the chain behind it; wait blocks until that slot's
  * results are on the host and reports them for the ranges the frame was submitted with. */
 int imgproc_submit(imgproc_ctx *ctx, int slot, const uint8_t *data, size_t stride, int w, int h);
+/* submit without the staging copy, for callers whose frames already sit in page-locked host memory (a camera
+ * driver's DMA ring, imgproc_host_alloc): the upload reads `data` itself, so it must stay untouched until
+ * imgproc_wait(slot) returns.  No counterpart in the reference (its frames arrive in a std::vector); with pageable
+ * memory the call still works but the runtime stages the copy itself and the call may block. */
+int imgproc_submit_pinned(imgproc_ctx *ctx, int slot, const uint8_t *data, size_t stride, int w, int h);
 int imgproc_wait(imgproc_ctx *ctx, int slot, imgproc_result *out);
 int imgproc_fetch_stage(imgproc_ctx *ctx, int slot, int stage, int range, uint8_t *dst, size_t dst_stride);
 
@@ -203,6 +208,9 @@ int imgproc_gaussian_taps(int ksize, int32_t *taps);
 int imgproc_dev_alloc(imgproc_ctx *ctx, size_t bytes, void **dptr);
 int imgproc_dev_free(imgproc_ctx *ctx, void *dptr);
 int imgproc_dev_upload(imgproc_ctx *ctx, void *dptr, const void *src, size_t bytes);
+/* page-locked host memory for imgproc_submit_pinned */
+int imgproc_host_alloc(imgproc_ctx *ctx, size_t bytes, void **hptr);
+int imgproc_host_free(imgproc_ctx *ctx, void *hptr);
 int imgproc_dev_download(imgproc_ctx *ctx, void *dst, const void *dptr, size_t bytes);
 
 /* ---- measurement ------------------------------------------------------------------------------

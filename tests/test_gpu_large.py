@@ -156,3 +156,48 @@ def test_pipelined_slots_stage_large_frames(oracle, padded):
     exp = oracle.chain(np.ascontiguousarray(frames[3]), post_blur_k=5, morph=morph, ranges=[DEFAULT_RANGE], stages=False)
     assert (got[3][1] == exp["mask"][0]).all()
     assert [got[3][0][0][k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")] == [int(v) for v in exp["moments"][0]]
+
+
+@pytest.mark.parametrize("padded", [False, True])
+@pytest.mark.parametrize("preset", ["baseline", "polygon_path"])
+def test_submit_pinned_skips_the_staging_copy(oracle, padded, preset):
+    """imgproc_submit_pinned: frames in page-locked memory (tight rows, and rows with a stride -> one 2-D DMA) go to the
+    device without the staging memcpy; three slots in flight; results equal imgproc_submit's, one frame the oracle's.
+    A pageable buffer is accepted too (the runtime stages it)."""
+    w, h, n = 1920, 1200, 6
+    kw = dict(post_blur_k=5, morph=ip.MORPH_BASELINE) if preset == "baseline" else dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH)
+    with ip.ImgProc(w, h, n_slots=3) as g:
+        g.set_pipeline(second_order=True, **kw)
+        g.set_ranges([DEFAULT_RANGE])
+        pinned = g.host_alloc((n, h, w + (40 if padded else 0), 3))
+        try:
+            pinned[:] = 201
+            views = []
+            for i in range(n):
+                pinned[i, :, :w] = synth_frame(w, h, 300 + i)
+                views.append(pinned[i, :, :w])
+            ref = []
+            for f in views:
+                r = g.process(np.ascontiguousarray(f))
+                ref.append((r, g.fetch_stage(0, L.STAGE_MASK)))
+            got = [None] * n
+            for i in range(n + 2):
+                if i >= 2:
+                    j = i - 2
+                    got[j] = (g.wait(j % 3), g.fetch_stage(j % 3, L.STAGE_MASK))
+                if i < n:
+                    g.submit_pinned(i % 3, views[i])
+            for i in range(n):
+                assert got[i][0] == ref[i][0], i
+                assert (got[i][1] == ref[i][1]).all(), i
+            g.submit_pinned(0, np.ascontiguousarray(views[2]))  # pageable memory: still correct
+            assert g.wait(0) == ref[2][0]
+            assert (g.fetch_stage(0, L.STAGE_HSV) == oracle.bgr2hsv(oracle.gaussian_blur(np.ascontiguousarray(views[2]), 3)
+                                                                     if preset == "polygon_path" else np.ascontiguousarray(views[2]))).all()
+            f4 = views[4].copy()  # before the page-locked block goes away
+        finally:
+            g.host_free(pinned)
+    exp = oracle.chain(f4, pre_blur_k=kw.get("pre_blur_k", 0), post_blur_k=5, morph=morph_tuples(kw["morph"]), ranges=[DEFAULT_RANGE],
+                       stages=False)
+    assert (got[4][1] == exp["mask"][0]).all()
+    assert [got[4][0][0][k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")] == [int(v) for v in exp["moments"][0]]
