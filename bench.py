@@ -5,7 +5,7 @@ frames/s of the full fused chain (5x5 Gaussian on HSV, HSV inRange, 3x3 erode + 
 GB/s of the chain kernel against the MI355X roofline and the CPU port of the same chain timed on the
 host's cores.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5|pp|pe]
 
 --gpus N > 1 without WORLD_SIZE in the environment: this process (which never touches the GPU) starts N
 rank processes itself, one per GPU, and relays rank 0's JSON line.  Under torch.distributed.run
@@ -23,6 +23,7 @@ Configurations (BASELINE.json `configs`):
   c4  configs[3]  3840x2160 BGR8, a 4096-frame stream per step cut into contiguous blocks by shard_bounds,
                   per-frame centroids gathered on rank 0                                                      (strong scaling)
   c5  configs[4]  7680x4320 BGR8, 15x15 Gaussian + 9x9 elliptical erode/dilate + 8 ranges, 4 frames per GPU per step
+  pp / pe         the reference nodes' own chains (polygon_path; pose_estimate with its commented blur + morphOps) at 1920x1200
 """
 from __future__ import annotations
 
@@ -68,6 +69,19 @@ def config_table():
                    workload="configs[3]: one step = a 4096-frame 3840x2160 BGR8 stream (a pool of 64 device-resident frames, "
                             "cycled) cut into contiguous per-rank blocks by shard_bounds, device batches of 64 frames, two in "
                             "flight; per-frame centroids gathered on rank 0 by frame id after the timed region"),
+        # not BASELINE configs: the reference nodes' own chains at the headline frame shape (two launches per batch)
+        "pp": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+                   pipe=dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH), ranges=[DEFAULT_RANGE],
+                   metric="frames/sec at 1920x1200 BGR8, polygon_path chain (3x3 Gaussian, HSV, 5x5 Gaussian, inRange, 14 erode/dilate, moments)",
+                   workload="objectPolygonPath.cpp:182-188,414-433 at 1920x1200 BGR8, device-resident batch of 256 frames per GPU per "
+                            "step: front kernel (blur3, HSV, blur5, inRange -> bit planes) + bit-plane morphology (E3x4 D8x2 E3x2 D8x2 "
+                            "E3x4 merged into 5 windows, moments, mask bytes)"),
+        "pe": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+                   pipe=dict(post_blur_k=5, morph=ip.MORPH_POSE_ESTIMATE), ranges=[DEFAULT_RANGE],
+                   metric="frames/sec at 1920x1200 BGR8, pose_estimate chain with its blur and morphOps enabled",
+                   workload="pose_estimate.cpp:203-206,405-415 (commented lines enabled) at 1920x1200 BGR8, device-resident batch of 256 "
+                            "frames per GPU per step: front kernel (HSV, blur5, inRange -> bit planes) + bit-plane morphology (E3x2 D8x2 "
+                            "E3x2 merged into 3 windows, moments, mask bytes)"),
         "c5": dict(w=7680, h=4320, enc=L.ENC_BGR8, batch=4, uniq=1, bpp=11, scaling="weak", hue_bands=tuple(bands),
                    pipe=dict(post_blur_k=15, morph=[ip.E(9, L.ELLIPSE), ip.D(9, L.ELLIPSE)]),
                    ranges=[((lo, 100, 80), (hi, 255, 255)) for lo, hi in bands],
@@ -464,13 +478,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "pp", "pe"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true", help="c3: skip the streamed (PCIe) leg")
     ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")
     ap.add_argument("--check", action="store_true", help="also verify one frame of the last batch against the oracle")
     args = ap.parse_args()
-    defaults = {"c2": (100, 20), "c3": (50, 10), "c4": (5, 1), "c5": (20, 4)}[args.config]
+    defaults = {"c2": (100, 20), "c3": (50, 10), "c4": (5, 1), "c5": (20, 4), "pp": (60, 10), "pe": (60, 10)}[args.config]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:

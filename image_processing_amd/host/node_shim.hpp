@@ -49,6 +49,11 @@ public:
         int mask_w = 0, mask_h = 0;
     };
 
+    // enable_blur_and_morph re-enables the node's commented-out lines :204 / :206.  The library then blurs the crop as an
+    // image of its own (BORDER_REFLECT_101 at the crop's edge); the reference's GaussianBlur on the submatrix
+    // Mat(pcaFrame, roi_) -- HSV inside the ROI after the in-place cvtColor, still BGR outside, no BORDER_ISOLATED --
+    // would read the parent's bytes there, so within the blur / morphology reach of the crop border this optional path
+    // is not what un-commenting the lines would compute.  The live chain (:203 + :205) is exact.
     explicit PoseEstimateShim(int device = 0, bool enable_blur_and_morph = false)
     {
         imgproc_config cfg = {device, FRAME_WIDTH, FRAME_HEIGHT, 2, 1};

@@ -19,7 +19,7 @@ def ours(name):
 
 
 def short(name):
-    return re.sub(r"^void ", "", name).split("(")[0]
+    return re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").split("(")[0]
 
 
 kern = collections.OrderedDict()
