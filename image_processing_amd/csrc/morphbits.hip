@@ -9,7 +9,9 @@
 // HBM traffic: 1 B/px read (+ halo from L2) and 1 B/px written instead of 2 B/px per op.
 #include "morphbits.h"
 
+#include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace ipm {
 
@@ -374,6 +376,269 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// Strip kernel for the reference's two morphOps lists on bit planes: no LDS tiles, no barriers, no halo recomputation
+// along x.  One WAVE owns a strip of 64 words (2048 px; a 1920-px row is one strip) of one plane and marches down a
+// segment of rows; lane = one 32-px word.  Every input row runs through all groups of the list in the same iteration:
+//   horizontal window AND: the 64-bit string (this word, right neighbour) re-based at x + lx from (left, this, right)
+//     -- neighbours by DPP -- then shift-doubling, 4 ops per step;
+//   vertical window AND: doubling over rows in registers (h & h[-1] -> p2, p2 & p2[-2] -> p4, p4 & p4[-4] -> p8; the
+//     row loop is unrolled 8x so every ring slot is a register name) and one last, overlapping combine with the level-P
+//     value of (height - P) rows ago (register ring, or a per-wave LDS ring with constant slots when that is > 2 rows);
+//   domain change for the next group: (out ^ flip) | out-of-image bits, one v_bitop3.
+// The list is a template argument (window offsets, heights and kinds are constants: no scalar loop control, no
+// per-group parameter registers -- a version with run-time lists spent more scalar than vector instructions and ran
+// no faster than the tile kernel).  Instantiated for morphOps of objectPolygonPath.cpp:416-432 (merged: E 9x9,
+// D 15x15 at -8..+6, E 5x5, D 15x15, E 9x9) and of pose_estimate.cpp:407-414 (E 5x5, D 15x15, E 5x5); every other list
+// stays with k_bitmorph.  ~24 VALU per group and 32-px word, against ~25 per word, group AND halo-inflated tile word
+// (x1.8 for polygon_path) plus index arithmetic there.
+// ---------------------------------------------------------------------------------------------
+struct WinC {  // one merged RECT window, as the planner's Group / Span holds it
+    int kind, lx, hx, dlo, dhi;
+};
+struct ListPolygonPath {
+    static constexpr int NG = 5;
+    static constexpr WinC get(int g)
+    {
+        constexpr WinC t[NG] = {{0, -4, 4, -4, 4}, {1, -8, 6, -8, 6}, {0, -2, 2, -2, 2}, {1, -8, 6, -8, 6}, {0, -4, 4, -4, 4}};
+        return t[g];
+    }
+};
+struct ListPoseEstimate {
+    static constexpr int NG = 3;
+    static constexpr WinC get(int g)
+    {
+        constexpr WinC t[NG] = {{0, -2, 2, -2, 2}, {1, -8, 6, -8, 6}, {0, -2, 2, -2, 2}};
+        return t[g];
+    }
+};
+
+template <class F, int... Is>
+__device__ __forceinline__ void bs_for_each(F &f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+struct StripArgs {
+    const uint32_t *tbits;  // [planes][h][twords]
+    int twords;
+    u8 *masks;  // [planes][h][w] or null
+    unsigned long long *mom;
+    int w, h, planes;
+    int hwl, valid_words, n_strips, seg_rows, n_segs, total_items;
+};
+
+constexpr int bs_pow2_le(int v) { return v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1; }
+
+template <class LIST, bool M2>
+__global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
+{
+    constexpr int NG = LIST::NG;
+    // per group: window height, doubling level, distance of the last combine; which groups keep that ring in LDS
+    constexpr int HT = [] { int s = 0; for (int g = 0; g < NG; g++) s += -LIST::get(g).dlo; return s; }();
+    constexpr int HB = [] { int s = 0; for (int g = 0; g < NG; g++) s += LIST::get(g).dhi; return s; }();
+    constexpr int N_LDS = [] { int n = 0; for (int g = 0; g < NG; g++) { const int H = LIST::get(g).dhi - LIST::get(g).dlo + 1; n += (H - bs_pow2_le(H)) > 2; } return n; }();
+    static_assert(N_LDS >= 0 && N_LDS <= NG, "ring count");
+    __shared__ uint32_t s_ring[4][N_LDS > 0 ? N_LDS : 1][8][64];  // per wave: the last 8 rows of a group's level-P results
+    __shared__ uint32_t s_lut[16];                                // nibble -> four 0/255 bytes
+    if (threadIdx.x < 16)
+        s_lut[threadIdx.x] = ((threadIdx.x & 1) ? 0xFFu : 0u) | ((threadIdx.x & 2) ? 0xFF00u : 0u) |
+                             ((threadIdx.x & 4) ? 0xFF0000u : 0u) | ((threadIdx.x & 8) ? 0xFF000000u : 0u);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (item >= a.total_items) return;  // whole waves leave; no barrier below
+    const int strip = item % a.n_strips;
+    const int rest = item / a.n_strips;
+    const int seg = rest % a.n_segs;
+    const int plane = rest / a.n_segs;
+    const int w = a.w, h = a.h;
+    const int ys = seg * a.seg_rows, ye = min(ys + a.seg_rows, h);
+    const int j = strip * a.valid_words - a.hwl + lane;  // this lane's word of the row
+    const int x0 = j * 32;
+    const bool in_row = j >= 0 && j < a.twords;
+    const bool writer = in_row && lane >= a.hwl && lane < a.hwl + a.valid_words;
+    uint32_t cinv = 0xFFFFFFFFu;  // bits outside the image (neutral in every group's erode domain)
+    if (in_row) cinv = x0 + 32 > w ? ~((1u << (w - x0)) - 1u) : 0u;
+    const uint32_t *src = a.tbits + (size_t)plane * h * a.twords + (in_row ? j : 0);
+    u8 *mrow = a.masks ? a.masks + (size_t)plane * w * h : nullptr;  // uniform
+
+    uint32_t prev1[NG], ring2[NG][2], ring4[NG][4], ringp[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        prev1[g] = ring2[g][0] = ring2[g][1] = ringp[g][0] = ringp[g][1] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 4; q++) ring4[g][q] = 0xFFFFFFFFu;
+    }
+    uint32_t m00 = 0, m01 = 0, bsa[5] = {0, 0, 0, 0, 0};  // first-order sums of this lane's word column (u32: <= 512 rows)
+    unsigned long long m20 = 0, m11 = 0, m02 = 0;
+    uint32_t(*ring)[8][64] = s_ring[wv];
+    const int r0 = ys - HT;  // first input row
+    const int n_iter = (ye - ys) + HT + HB;
+    auto load = [&](int r) -> uint32_t {
+        const bool ok = in_row && r >= 0 && r < h;
+        return ok ? src[(size_t)r * a.twords] : 0u;
+    };
+    constexpr uint32_t km_first = LIST::get(0).kind ? 0xFFFFFFFFu : 0u, km_last = LIST::get(NG - 1).kind ? 0xFFFFFFFFu : 0u;
+    uint32_t nxt0 = load(r0), nxt1 = load(r0 + 1), nxt2 = load(r0 + 2);
+    // whole batches of 8 rows (ring slots are register names): the rows a last, partial batch runs beyond the segment are
+    // computed and dropped
+    for (int ib = 0; ib < n_iter; ib += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int r = r0 + ib + u;
+            const uint32_t in = nxt0;
+            nxt0 = nxt1;
+            nxt1 = nxt2;
+            nxt2 = load(r + 3);
+            uint32_t x = (in ^ km_first) | cinv | ((r >= 0 && r < h) ? 0u : 0xFFFFFFFFu);
+            auto group = [&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr WinC W = LIST::get(g);
+                constexpr int ex = 32 + W.lx, len = W.hx - W.lx + 1;
+                constexpr int H = W.dhi - W.dlo + 1, P = bs_pow2_le(H), dist = H - P;
+                // rows of reach below summed over groups 0..g, and the LDS ring this group uses (if any)
+                constexpr int below = [] { int b = 0; for (int q = 0; q <= g; q++) b += LIST::get(q).dhi; return b; }();
+                constexpr int lds_i = [] { int n = 0; for (int q = 0; q < g; q++) { const int h2 = LIST::get(q).dhi - LIST::get(q).dlo + 1; n += (h2 - bs_pow2_le(h2)) > 2; } return n; }();
+                // ---- horizontal: AND of bits x+lx .. x+hx ----
+                const uint32_t R = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x130, 0xF, 0xF, true);  // lane+1 (lane 63: 0, halo)
+                uint32_t b0 = x, b1 = R;
+                if (ex != 32) {
+                    const uint32_t L = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xF, 0xF, true);  // lane-1
+                    b0 = funnel(x, L, ex);
+                    b1 = funnel(R, x, ex);
+                }
+                if (len >= 2) { b0 &= funnel(b1, b0, 1); if (len > 2) b1 &= funnel(0xFFFFFFFFu, b1, 1); }
+                if (len >= 4) { b0 &= funnel(b1, b0, 2); if (len > 4) b1 &= funnel(0xFFFFFFFFu, b1, 2); }
+                if (len >= 8) { b0 &= funnel(b1, b0, 4); if (len > 8) b1 &= funnel(0xFFFFFFFFu, b1, 4); }
+                if (len >= 16) { b0 &= funnel(b1, b0, 8); if (len > 16) b1 &= funnel(0xFFFFFFFFu, b1, 8); }
+                if (len >= 32) { b0 &= funnel(b1, b0, 16); if (len > 32) b1 &= funnel(0xFFFFFFFFu, b1, 16); }
+                constexpr int have = len >= 32 ? 32 : len >= 16 ? 16 : len >= 8 ? 8 : len >= 4 ? 4 : len >= 2 ? 2 : 1;
+                if (have < len) b0 &= funnel(b1, b0, len - have);  // the window is two overlapping runs of `have` bits
+                // ---- vertical: AND of this and the previous height-1 rows of b0 ----
+                uint32_t out = b0;
+                if (P >= 2) {
+                    out = b0 & prev1[g];
+                    prev1[g] = b0;
+                }
+                if (P >= 4) {
+                    const uint32_t p2 = out;
+                    out = p2 & ring2[g][u & 1];
+                    ring2[g][u & 1] = p2;
+                }
+                if (P >= 8) {
+                    const uint32_t p4 = out;
+                    out = p4 & ring4[g][u & 3];
+                    ring4[g][u & 3] = p4;
+                }
+                if (dist > 2) {  // the level-P value of `dist` rows ago: LDS ring, constant slots
+                    ring[lds_i][u][lane] = out;
+                    __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering
+                    out &= ring[lds_i][(u - dist) & 7][lane];
+                    __builtin_amdgcn_wave_barrier();
+                } else if (dist > 0) {  // 1 or 2 rows ago: two registers
+                    const uint32_t pp = out;
+                    out = pp & ringp[g][(u - dist) & 1];
+                    ringp[g][u & 1] = pp;
+                }
+                // ---- into the next group's erode domain; its rows outside the image are neutral ----
+                if (g + 1 < NG) {
+                    constexpr uint32_t flip = (W.kind != LIST::get(g + 1 < NG ? g + 1 : g).kind) ? 0xFFFFFFFFu : 0u;
+                    const int yg = r - below;
+                    x = (out ^ flip) | cinv | ((yg >= 0 && yg < h) ? 0u : 0xFFFFFFFFu);
+                } else {
+                    x = out;
+                }
+            };
+            bs_for_each(group, std::make_integer_sequence<int, NG>{});
+            const int y = r - HB;
+            const bool row_out = y >= ys && y < ye;  // uniform: the pipeline is still filling / past the segment
+            const uint32_t bits = row_out ? (x ^ km_last) & ~cinv : 0u;
+            if (a.masks && row_out) {
+                // Bytes out, each store instruction one contiguous KB per wave: lane l takes the 16 pixels
+                // [16 l, 16 l + 16) of the strip's first (second) 1024 from lane l/2 (32 + l/2) through the LDS crossbar
+                // (a lane storing its own 32 bytes would leave every 64-byte line to two instructions).
+                const uint32_t wbits = writer ? bits : 0u;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int sl = 32 * half + (lane >> 1);  // source lane = word of the strip
+                    const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(sl * 4, (int)wbits);
+                    const uint32_t b16 = (lane & 1) ? word >> 16 : word;
+                    uint32_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t i4 = (q == 0 ? (b16 << 2) : (b16 >> (4 * q - 2))) & 60u;
+                        o[q] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_lut) + i4);
+                    }
+                    const int xs = (strip * a.valid_words - a.hwl + sl) * 32 + 16 * (lane & 1);  // first pixel of this lane's piece
+                    const bool src_writer = sl >= a.hwl && sl < a.hwl + a.valid_words;
+                    const int nd = src_writer && xs >= 0 ? min(4, (w - xs) >> 2) : 0;  // dwords inside the row (w % 4 == 0)
+                    if (nd > 0) {
+                        uint32_t *o32 = reinterpret_cast<uint32_t *>(mrow + (size_t)y * w + xs);
+                        if (nd == 4) {
+                            *reinterpret_cast<uint4 *>(o32) = make_uint4(o[0], o[1], o[2], o[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 3; q++)
+                                if (q < nd) o32[q] = o[q];
+                        }
+                    }
+                }
+            }
+            if (writer) {
+                const uint32_t cnt = __popc(bits);
+                m00 += cnt;
+                m01 = __umul24(cnt, (uint32_t)(y - ys)) + m01;  // relative to the segment: fits 32 bits for any h
+                bsa[0] += __popc(bits & 0xAAAAAAAAu);
+                bsa[1] += __popc(bits & 0xCCCCCCCCu);
+                bsa[2] += __popc(bits & 0xF0F0F0F0u);
+                bsa[3] += __popc(bits & 0xFF00FF00u);
+                bsa[4] += __popc(bits & 0xFFFF0000u);
+                if (M2 && bits) {
+                    const uint32_t B[5] = {0xAAAAAAAAu, 0xCCCCCCCCu, 0xF0F0F0F0u, 0xFF00FF00u, 0xFFFF0000u};
+                    unsigned long long bs = 0, bs2 = 0;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        bs += (unsigned long long)__popc(bits & B[q]) << q;
+                        bs2 += (unsigned long long)__popc(bits & B[q]) << (2 * q);
+#pragma unroll
+                        for (int kk = q + 1; kk < 5; kk++) bs2 += (unsigned long long)__popc(bits & B[q] & B[kk]) << (q + kk + 1);
+                    }
+                    const unsigned long long X = (unsigned long long)(uint32_t)x0;
+                    m20 += X * X * cnt + 2ull * X * bs + bs2;
+                    m11 += (unsigned long long)(uint32_t)y * (X * cnt + bs);
+                    m02 += (unsigned long long)(uint32_t)y * (uint32_t)y * cnt;
+                }
+            }
+        }
+    }
+    // sum of x over this lane's set bits = x0 * count + sum of bit indices
+    unsigned long long s0 = m00, s2 = (unsigned long long)m01 + (unsigned long long)(uint32_t)ys * m00;
+    unsigned long long s1 = (unsigned long long)(uint32_t)(in_row ? x0 : 0) * m00 + bsa[0] + 2ull * bsa[1] + 4ull * bsa[2] + 8ull * bsa[3] + 16ull * bsa[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+        if (M2) {
+            m20 += __shfl_down(m20, off, 64);
+            m11 += __shfl_down(m11, off, 64);
+            m02 += __shfl_down(m02, off, 64);
+        }
+    }
+    if (lane == 0 && s0) {
+        unsigned long long *o = a.mom + (size_t)plane * 6;
+        atomicAdd(o + 0, s0);
+        atomicAdd(o + 1, s1);
+        atomicAdd(o + 2, s2);
+        if (M2) {
+            atomicAdd(o + 3, m20);
+            atomicAdd(o + 4, m11);
+            atomicAdd(o + 5, m02);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: turn the pipeline's element list into groups
 // ---------------------------------------------------------------------------------------------
 namespace {
@@ -465,12 +730,76 @@ bool plan_bitmorph(const imgproc_pipeline &pipe, const ipk::Element *elems, Plan
     return true;
 }
 
+// Does the planner's list equal one of the lists the strip kernel is instantiated for?
+template <class LIST>
+static bool strip_matches(const Plan &plan)
+{
+    if ((int)plan.groups.size() != LIST::NG || plan.hwl > 1 || plan.hwr > 1) return false;
+    for (int g = 0; g < LIST::NG; g++) {
+        const Group &G = plan.groups[g];
+        if (G.n_spans != 1 || G.spans[0].rows != 0) return false;
+        const Span &sp = G.spans[0];
+        const WinC c = LIST::get(g);
+        if (G.kind != c.kind || sp.lx != c.lx || sp.hx != c.hx || sp.dy_lo != c.dlo || sp.dy_hi != c.dhi) return false;
+    }
+    return true;
+}
+
+static int g_bs_seg_rows = -1, g_bs_mode = -1;  // IMGPROC_BITSTRIP: 0 never, 1 when the job is large (default), 2 whenever the list matches
+
+template <class LIST>
+static hipError_t launch_bitstrip(const Plan &plan, const uint32_t *d_tbits, u8 *d_masks, unsigned long long *d_mom, int w,
+                                  int h, int planes, int second_order, hipStream_t stream)
+{
+    StripArgs a{};
+    a.tbits = d_tbits;
+    a.twords = (w + 31) / 32;
+    a.masks = d_masks;
+    a.mom = d_mom;
+    a.w = w; a.h = h; a.planes = planes;
+    a.hwl = plan.hwl;
+    a.valid_words = a.twords <= 64 - plan.hwl - plan.hwr ? a.twords : 64 - plan.hwl - plan.hwr;
+    a.n_strips = (a.twords + a.valid_words - 1) / a.valid_words;
+    // Segments: every segment re-runs the list's rows of reach, so they should be long; the chip wants a few thousand
+    // waves.  ~4000 waves when the job has them, at least 1.5 x the reach and 48 rows, at most 512 (u32 sums per lane).
+    const int reach = plan.ht + plan.hb;
+    const long long cols = (long long)planes * a.n_strips;
+    int seg = g_bs_seg_rows > 0 ? g_bs_seg_rows : (int)((long long)h * cols / 4096);
+    if (g_bs_seg_rows <= 0 && seg < reach + reach / 2) seg = reach + reach / 2;
+    seg = seg < 48 ? 48 : seg > 512 ? 512 : seg;
+    a.n_segs = (h + seg - 1) / seg;
+    a.seg_rows = (h + a.n_segs - 1) / a.n_segs;
+    const long long items = cols * a.n_segs;
+    if (items > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    a.total_items = (int)items;
+    const dim3 grid((unsigned)((items + 3) / 4));
+    if (second_order)
+        hipLaunchKernelGGL((k_bitstrip<LIST, true>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k_bitstrip<LIST, false>), grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_bitmorph(const Plan &plan, const Group *d_groups, const u8 *d_thresh, u8 *d_masks,
                            unsigned long long *d_mom, int w, int h, int planes, int second_order, hipStream_t stream,
                            const uint32_t *d_tbits)
 {
     if (planes <= 0 || w <= 0 || h <= 0) return hipSuccess;
     if (w >= (1 << 24) || h >= (1 << 24)) return hipErrorInvalidValue;  // 24-bit multiplies in the moment sums
+    {  // read on every launch (cheap next to one): tests and A/B runs switch it inside a process
+        const char *e = getenv("IMGPROC_BITSTRIP");
+        g_bs_mode = e ? atoi(e) : 1;
+        const char *r = getenv("IMGPROC_BITSTRIP_SEG_ROWS");
+        g_bs_seg_rows = r ? atoi(r) : 0;
+    }
+    // the reference's two lists on bit planes, with enough independent columns to fill the chip: the strip kernel
+    const long long strip_waves = (long long)planes * (((w + 31) / 32 + 61) / 62) * ((h + 63) / 64);
+    if (d_tbits && g_bs_mode > 0 && (w & 3) == 0 && (g_bs_mode > 1 || strip_waves >= 512)) {
+        if (strip_matches<ListPolygonPath>(plan))
+            return launch_bitstrip<ListPolygonPath>(plan, d_tbits, d_masks, d_mom, w, h, planes, second_order, stream);
+        if (strip_matches<ListPoseEstimate>(plan))
+            return launch_bitstrip<ListPoseEstimate>(plan, d_tbits, d_masks, d_mom, w, h, planes, second_order, stream);
+    }
     Args a{};
     a.thresh = d_tbits ? nullptr : d_thresh;
     a.tbits = d_tbits;

@@ -492,3 +492,43 @@ def test_up_to_eight_ranges_in_one_launch(gpu, oracle, nr, preset):
     for r in range(nr):
         assert (gpu.fetch_stage(0, L.STAGE_MASK, r) == exp["mask"][r]).all()
         check_moments(res1[r], exp["moments"][r], second=True)
+
+
+@pytest.mark.parametrize("preset", ["polygon_path", "pose_estimate_full"])
+@pytest.mark.parametrize("hw", [(4, 8), (37, 64), (100, 252), (123, 516), (300, 1920), (211, 2100), (96, 4096)])
+@pytest.mark.parametrize("seg_rows", [0, 48])
+def test_bit_plane_strip_kernel(gpu, oracle, monkeypatch, preset, hw, seg_rows):
+    """The strip form of the bit-plane morphology (instantiated for the two morphOps lists of the reference; normally
+    taken only for large jobs) forced on small and wide frames: one strip and several, several segments per plane, words
+    cut by the right edge; equal to the oracle and to the tile kernel, second-order sums included."""
+    h, w = hw
+    n = 2
+    kw = PRESETS[preset]
+    frames = np.random.default_rng(h + w).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    frames[:, h // 5: h - h // 6, w // 7: w - w // 5] //= 3  # a large dark region: something survives the erosions
+    ranges = [((0, 0, 0), (256, 256, 110)), DEFAULT_RANGE]
+    out = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("IMGPROC_BITSTRIP", mode)
+        if seg_rows:
+            monkeypatch.setenv("IMGPROC_BITSTRIP_SEG_ROWS", str(seg_rows))
+        with ip.ImgProc(w, h, n_slots=1, max_batch=n) as g:
+            g.set_pipeline(second_order=True, **kw)
+            g.set_ranges(ranges)
+            d_in, d_out = g.dev_alloc(frames.nbytes), g.dev_alloc(n * 2 * w * h)
+            try:
+                g.dev_upload(d_in, frames)
+                res = g.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, d_out)
+                out[mode] = (res, g.dev_download(d_out, (n, 2, h, w)))
+            finally:
+                g.dev_free(d_in)
+                g.dev_free(d_out)
+    assert out["2"][0] == out["0"][0]
+    assert (out["2"][1] == out["0"][1]).all()
+    for i in range(n):
+        exp = oracle.chain(frames[i], pre_blur_k=kw["pre_blur_k"], post_blur_k=kw["post_blur_k"], morph=morph_tuples(kw["morph"]),
+                           ranges=ranges, stages=False)
+        for r in range(2):
+            assert (out["2"][1][i, r] == exp["mask"][r]).all(), (preset, hw, i, r)
+            check_moments(out["2"][0][i][r], exp["moments"][r], second=True)
+    assert sum(int(m[0]) for m in exp["moments"]) > 0 or h < 30
