@@ -324,6 +324,66 @@ __device__ __forceinline__ void hsv_row_pairs(const Pairs &p, const char *tab, R
     o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
 }
 
+// 16-bit field H of w, masked to a multiple of 4 (bits 2..9), in one SDWA and: the interpolated Bayer channels are kept
+// as "4 x value plus junk in bits 0..1" so that this is their whole extraction
+template <int H>
+__device__ __forceinline__ uint32_t word_and_x4(uint32_t w)
+{
+    uint32_t r;
+    const uint32_t m = 0x3FCu;
+    if (H == 0)
+        asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(m), "v"(w));
+    else
+        asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(m), "v"(w));
+    return r;
+}
+
+// Demosaic + HSV of one fed row without the 8-bit intermediate (the no-pre-blur Bayer chain, BASELINE config 3).
+// The four-neighbour averages leave (sum + 2) and the two-neighbour averages (2 sum + 2) in their fields: both are
+// 4 x the rounded average plus junk in bits 0..1, which word_and_x4 drops while it extracts -- one op per value
+// instead of shift + mask per pair and a shift per value.  Arithmetic identical to demosaic_row + hsv_row_pairs:
+// 4 ((a+b+c+d+2) >> 2) = (a+b+c+d+2) & ~3 and 4 ((a+b+1) >> 1) = (2a+2b+2) & ~3.
+__device__ __forceinline__ void demosaic_hsv_row(const uint32_t (&w)[3], bool odd_row, int border_strip, bool first_col,
+                                                 bool last_col, const char *tab, Row &o)
+{
+    const uint32_t M8 = 0x00FF00FFu, C2 = 0x00020002u;
+    const uint32_t me = w[1] & M8, mo = __builtin_amdgcn_perm(w[1], w[1], 0x0C030C01u);  // even / odd columns of the centre row
+    const uint32_t vse = (w[0] & M8) + (w[2] & M8);                                        // up + down, even columns
+    const uint32_t vso = __builtin_amdgcn_perm(w[0], w[0], 0x0C030C01u) + __builtin_amdgcn_perm(w[2], w[2], 0x0C030C01u);
+    const uint32_t hme = mo + alignbit(mo, from_left(mo), 16);   // left + right of the even columns
+    const uint32_t hmo = me + alignbit(from_right(me), me, 16);  // left + right of the odd columns
+    uint32_t c4[4][3];  // pixel k: 4b, 4g, 4r (pixel k sits in pair k & 1, field k >> 1)
+    if (!odd_row) {  // R G R G: even columns are R sites, odd columns G with R left/right and B above/below
+        const uint32_t hve = vso + alignbit(vso, from_left(vso), 16);  // the four diagonals of the even columns
+        const uint32_t g0 = hme + vse + C2, b0 = hve + C2;             // even columns: G, B
+        const uint32_t r1 = (hmo << 1) + C2, b1 = (vso << 1) + C2;     // odd columns: R, B
+        c4[0][0] = word_and_x4<0>(b0); c4[0][1] = word_and_x4<0>(g0); c4[0][2] = word_x4<0>(me);
+        c4[2][0] = word_and_x4<1>(b0); c4[2][1] = word_and_x4<1>(g0); c4[2][2] = word_x4<1>(me);
+        c4[1][0] = word_and_x4<0>(b1); c4[1][1] = word_x4<0>(mo); c4[1][2] = word_and_x4<0>(r1);
+        c4[3][0] = word_and_x4<1>(b1); c4[3][1] = word_x4<1>(mo); c4[3][2] = word_and_x4<1>(r1);
+    } else {  // G B G B: odd columns are B sites, even columns G with B left/right and R above/below
+        const uint32_t hvo = vse + alignbit(from_right(vse), vse, 16);
+        const uint32_t b0 = (hme << 1) + C2, r0 = (vse << 1) + C2;     // even columns: B, R
+        const uint32_t g1 = hmo + vso + C2, r1 = hvo + C2;             // odd columns: G, R
+        c4[0][0] = word_and_x4<0>(b0); c4[0][1] = word_x4<0>(me); c4[0][2] = word_and_x4<0>(r0);
+        c4[2][0] = word_and_x4<1>(b0); c4[2][1] = word_x4<1>(me); c4[2][2] = word_and_x4<1>(r0);
+        c4[1][0] = word_x4<0>(mo); c4[1][1] = word_and_x4<0>(g1); c4[1][2] = word_and_x4<0>(r1);
+        c4[3][0] = word_x4<1>(mo); c4[3][1] = word_and_x4<1>(g1); c4[3][2] = word_and_x4<1>(r1);
+    }
+    if (border_strip) {  // OpenCV leaves no interpolated border: column 0 copies column 1, column w-1 copies w-2
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (first_col) c4[0][c] = c4[1][c];
+            if (last_col) c4[3][c] = c4[2][c];
+        }
+    }
+    uint32_t vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hsv_px<false>(c4[k][0], c4[k][1], c4[k][2], tab, o.hs[k], vv[k]);
+    o.v[0] = (vv[0] | (vv[1] << 16)) >> 2;
+    o.v[1] = (vv[2] | (vv[3] << 16)) >> 2;
+}
+
 __device__ __forceinline__ void pairs_to_row(const Pairs &p, RowBGR &o)
 {
     o.c01[0] = __builtin_amdgcn_perm(p.g[0], p.b[0], 0x05040100u);
@@ -497,7 +557,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     auto bayer_row = [&](int f) { return min(max(reflect_row(r_first + f, h), 1), h - 2); };  // border rows copy too
     auto convert = [&](int sl, bool have_rows, int f) {
         Pairs bp;
-        if (BAYER) demosaic_row(raw[sl], bayer_row(f) & 1, border_strip, first_col, last_col, bp);
+        if (BAYER && PRE_K == 3) demosaic_row(raw[sl], bayer_row(f) & 1, border_strip, first_col, last_col, bp);
         if (PRE_K == 3) {
             if (BAYER)
                 pairs_to_row(bp, rawp[sl & (PRE_K == 3 ? 7 : 0)]);
@@ -507,7 +567,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
                 preblur_hsv_row<RGB>(rawp[(sl + 6) & (PRE_K == 3 ? 7 : 0)], rawp[(sl + 7) & (PRE_K == 3 ? 7 : 0)],
                                      rawp[sl & (PRE_K == 3 ? 7 : 0)], border_strip, lb_halo, rb_halo, tab, ring[sl]);
         } else if (BAYER) {
-            hsv_row_pairs(bp, tab, ring[sl]);
+            demosaic_hsv_row(raw[sl], bayer_row(f) & 1, border_strip, first_col, last_col, tab, ring[sl]);
         } else {
             hsv_row<RGB>(raw[sl], tab, ring[sl]);
         }
