@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libimgproc_hip.so")
 SOURCES = ["api.hip", "kernels.hip", "fused.hip", "fused_inst_plain_small.hip", "fused_inst_plain_large.hip",
-           "fused_inst_bayer_small.hip", "fused_inst_bayer_large.hip", "morphbits.hip", "gauss.hip"]
+           "fused_inst_bayer_small.hip", "fused_inst_bayer_large.hip", "morphbits.hip", "gauss.hip", "gauss_mfma.hip"]
 HEADERS = ["kernels.h", "fused.h", "fused_kernel.hpp", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread"]
 

@@ -32,6 +32,10 @@ hipError_t launch_bgr2hsv(const u8 *src, size_t sstride, u8 *dst, size_t dstride
 hipError_t launch_gaussian(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int cn,
                            const Taps &taps, hipStream_t stream);
 // strip kernel (gauss.hip): odd k <= 15, symmetric taps summing to 256, 4-byte aligned source rows
+// long kernels (k = 7..15) as banded contractions on the matrix cores (gauss_mfma.hip)
+bool gaussian_mfma_ok(const u8 *src, size_t sstride, int w, int h, int cn, const Taps &taps);
+hipError_t launch_gaussian_mfma(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int cn,
+                                const Taps &taps, hipStream_t stream);
 bool gaussian_strip_ok(const u8 *src, size_t sstride, int w, int h, int cn, const Taps &taps);
 hipError_t launch_gaussian_strip(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int cn,
                                  const Taps &taps, hipStream_t stream);

@@ -140,6 +140,12 @@ hipError_t launch_gaussian(const u8 *src, size_t sstride, u8 *dst, size_t dstrid
     if (w <= 0 || h <= 0) return hipSuccess;
     if ((cn != 1 && cn != 3) || taps.k < 1 || taps.k > 31 || !(taps.k & 1)) return hipErrorInvalidValue;
     static const bool generic_only = getenv("IMGPROC_GAUSS_GENERIC") != nullptr;  // test hook: tile kernel only
+    {  // k >= 7: the matrix-core kernel (IMGPROC_GAUSS_MFMA=0: A/B and tests; read per call, cheap next to a launch)
+        const char *e = getenv("IMGPROC_GAUSS_MFMA");
+        if (!generic_only && !(e && e[0] == '0') && gaussian_mfma_ok(src, sstride, w, h, cn, taps) &&
+            (unsigned long long)dstride * (unsigned long long)h < (1ull << 32))
+            return launch_gaussian_mfma(src, sstride, dst, dstride, w, h, cn, taps, stream);
+    }
     if (!generic_only && gaussian_strip_ok(src, sstride, w, h, cn, taps))
         return launch_gaussian_strip(src, sstride, dst, dstride, w, h, cn, taps, stream);
     dim3 grid((w * cn + G_TWB - 1) / G_TWB, (h + G_TH - 1) / G_TH);
