@@ -138,3 +138,20 @@ def test_errors(gpu):
     assert e.value.status == L.ESTATE
     with pytest.raises(ip.ImgProcError):
         gpu.morphology(np.zeros((4, 4), np.uint8), ip.MorphOp(L.ERODE, L.RECT, 40, 3))
+
+
+@pytest.mark.parametrize("hw,cn,k", [((1000, 1234), 3, 15), ((700, 2051), 1, 15), ((333, 901), 3, 9), ((40, 4096), 3, 7), ((1200, 1920), 3, 15)])
+def test_gaussian_long_kernels_on_matrix_cores(oracle, monkeypatch, hw, cn, k):
+    """k = 7..15 run as banded i8 contractions on the MFMA units (gauss_mfma.hip): several 16-row segments and 64-byte
+    strips per image, row bytes that are no multiple of 64 or of 8, reflect-101 on all four borders; bit-identical to the
+    oracle and to the strip kernel (IMGPROC_GAUSS_MFMA=0)."""
+    rng = np.random.default_rng(hw[0] + hw[1] + k)
+    img = rng.integers(0, 256, hw + ((3,) if cn == 3 else ()), dtype=np.uint8)
+    img[: hw[0] // 3] |= 0xF0  # bright rows: sums near the top of the 8.8 range
+    exp = oracle.gaussian_blur(img, k)
+    with ip.ImgProc(hw[1], hw[0], n_slots=1) as g:
+        got = g.GaussianBlur(img, k)
+        monkeypatch.setenv("IMGPROC_GAUSS_MFMA", "0")
+        other = g.GaussianBlur(img, k)
+    assert (got == exp).all()
+    assert (other == exp).all()
