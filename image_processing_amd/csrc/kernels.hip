@@ -244,80 +244,138 @@ __global__ __launch_bounds__(256) void k_in_range(const u8 *__restrict__ src, si
     }
 }
 
-// The same test with the result as bit planes (what the bit-plane morphology wants, morphbits.hip): 32 pixels per lane,
-// plane r's word j = bit i set iff pixel 32 j + i lies in range r.  1/8 B per pixel and range instead of 1 B.
-__global__ __launch_bounds__(256) void k_in_range_bits(const u8 *__restrict__ src, size_t sstride, uint32_t *__restrict__ dst,
-                                                       int words, int w, int h, Bounds b, int align)
+// The same test with the result as bit planes (what the bit-plane morphology wants, morphbits.hip): plane r's word j =
+// bit i set iff pixel 32 j + i lies in range r.  1/8 B per pixel and range instead of 1 B.
+// A wave takes a run of 256-pixel chunks; lane = 4 pixels = 3 dwords, so a chunk is one contiguous 768-byte load.
+// The tables hold DWORDS here, bit 4 r = "value inside range r": the AND of a pixel's three entries is its membership
+// spread over the eight nibbles, four pixels shifted by 0..3 fill the nibbles, and an 8x8 nibble transpose across the
+// 8 lanes of a 32-pixel word leaves word j of plane r in lane 8 j + r.  ~45 vector instructions per 256 pixels.
+__device__ __forceinline__ uint32_t byte_x4(uint32_t w, uint32_t two, int k)  // 4 * byte k of w, one SDWA shift
 {
-    __shared__ u8 s_t[3][256];
+    uint32_t r;
+    switch (k) {
+    case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w)); break;
+    case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w)); break;
+    case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w)); break;
+    default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w)); break;
+    }
+    return r;
+}
+
+// FAST: rows and base are dword-aligned and w % 4 == 0, so a lane's 12 bytes are wholly inside or wholly outside the row.
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_in_range_bits(const u8 *__restrict__ src, size_t sstride, uint32_t *__restrict__ dst,
+                                                       int words, int w, int h, Bounds b, int chunks_per_row,
+                                                       int chunks_per_wave, int total_chunks)
+{
+    __shared__ uint32_t s_t[3][256];
     {
-        const int v = threadIdx.y * 64 + threadIdx.x;
+        const int v = threadIdx.x;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            unsigned m = 0;
-            for (int r = 0; r < b.n; r++) m |= (v >= b.lo[r][c] && v <= b.hi[r][c]) ? (1u << r) : 0u;
-            s_t[c][v] = (u8)m;
+            uint32_t m = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++)  // constant indices: the bounds stay in scalar registers
+                m |= (r < b.n && v >= b.lo[r][c] && v <= b.hi[r][c]) ? (1u << (4 * r)) : 0u;
+            s_t[c][v] = m;
         }
     }
     __syncthreads();
-    const int j = blockIdx.x * 64 + threadIdx.x;  // word index in the row
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= h || j >= words) return;
-    const int x0 = j * 32, n = min(32, w - x0);
-    const u8 *s = src + (size_t)y * sstride + (size_t)x0 * 3;
-    uint32_t raw[24];
-    if (align == 16 && n == 32) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(s);
+    const int lane = threadIdx.x & 63;
+    const int first = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * chunks_per_wave);
+    if (first >= total_chunks) return;  // whole waves leave; no barrier below
+    const int n_ch = min(chunks_per_wave, total_chunks - first);
+    int y = first / chunks_per_row, cx = first - y * chunks_per_row;
+    // 8x8 nibble transpose across the lanes of a word: butterflies with lane ^ 4, ^ 2, ^ 1 (partner by ds_swizzle)
+    const uint32_t sel4 = (lane & 4) ? 0x03020706u : 0x05040100u;  // v_perm_b32(partner, own, sel)
+    const uint32_t sel2 = (lane & 2) ? 0x03070105u : 0x06020400u;
+    const uint32_t m1 = (lane & 1) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+    const uint32_t rot1 = (lane & 1) ? 4u : 28u;
+    const uint32_t two = 2u;
+    const char *tab = reinterpret_cast<const char *>(&s_t[0][0]);
+    const int r = lane & 7;
+    uint32_t *const dplane = dst + (size_t)r * h * words;  // this lane's plane (h * words < 2^31: checked at launch)
+    auto fetch = [&](int yy, int cc, uint32_t (&d)[3]) {
+        const int x0 = cc * 256 + lane * 4;
+        const u8 *s = src + (size_t)yy * sstride + (uint32_t)(x0 * 3);
+        if (FAST) {
+            // no branch around the load (a skipped load would make the compiler wait for ALL loads at the join, the one just
+            // issued for the next chunk included): lanes beyond the row re-read its last 4 pixels, their bits are dropped
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)yy * sstride + (uint32_t)(min(x0, w - 4) * 3));
+            d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+        } else {
+            const int nb = 3 * (w - x0);  // bytes of this lane's 12 that lie inside the row (may be <= 0)
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const uint4 q = p[i];
-            raw[4 * i] = q.x; raw[4 * i + 1] = q.y; raw[4 * i + 2] = q.z; raw[4 * i + 3] = q.w;
+            for (int i = 0; i < 3; i++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (4 * i + q < nb) v |= (uint32_t)s[4 * i + q] << (8 * q);
+                d[i] = v;
+            }
         }
-    } else if (align >= 4 && n == 32) {
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(s);
-#pragma unroll
-        for (int i = 0; i < 24; i++) raw[i] = p[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 24; i++) {
-            uint32_t v = 0;
-            for (int q = 0; q < 4; q++)
-                if ((4 * i + q) < 3 * n) v |= (uint32_t)s[4 * i + q] << (8 * q);
-            raw[i] = v;
-        }
-    }
-    uint32_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int g = 0; g < 8; g++) {  // 4 pixels = 3 dwords at a time
-        uint32_t m4 = 0;           // byte k = range set of pixel 4 g + k
+    };
+    auto advance = [&](int &yy, int &cc) {
+        if (++cc == chunks_per_row) cc = 0, yy++;
+    };
+    auto process = [&](const uint32_t (&d)[3], int yy, int cc) {
+        uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t m = 0xFFu;
+            uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const int bi = 12 * g + 3 * k + c;
-                m &= s_t[c][(raw[bi >> 2] >> (8 * (bi & 3))) & 255u];
+                const int bi = 3 * k + c;
+                m &= *reinterpret_cast<const uint32_t *>(tab + 1024 * c + byte_x4(d[bi >> 2], two, bi & 3));
             }
-            m4 |= m << (8 * k);
+            acc |= m << k;
         }
-        // bit r of the four bytes -> four consecutive bits of plane r's word (one 4 x 8-bit dot product per range)
-        for (int r = 0; r < b.n; r++) {
-            const uint32_t t = (m4 >> r) & 0x01010101u;
-            out[r] |= __builtin_amdgcn_udot4(t, 0x08040201u, 0u, false) << (4 * g);
-        }
+        uint32_t q = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x101F);  // lane ^ 4
+        acc = __builtin_amdgcn_perm(q, acc, sel4);
+        q = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x081F);  // lane ^ 2
+        acc = __builtin_amdgcn_perm(q, acc, sel2);
+        q = (uint32_t)__builtin_amdgcn_ds_swizzle((int)acc, 0x041F);  // lane ^ 1
+        acc = (acc & m1) | (__builtin_amdgcn_alignbit(q, q, rot1) & ~m1);
+        // lane 8 j + r: word j of this chunk, plane r.  Pixels beyond w matched the tables on zero bytes: cleared.
+        const int j = cc * 8 + (lane >> 3);
+        const int n = w - j * 32;
+        const uint32_t keep = n >= 32 ? 0xFFFFFFFFu : ((1u << max(n, 0)) - 1u);
+        if (r < b.n && j < words) dplane[(uint32_t)(yy * words + j)] = acc & keep;
+    };
+    // two chunks in flight: the next one's load is issued before this one's table lookups.  The loads run up to two
+    // chunks beyond the wave's run (the next wave's chunks; beyond the image the last row again) rather than branch.
+    uint32_t da[3], db[3];
+    fetch(y, cx, da);
+    for (int i = 0; i < n_ch; i += 2) {
+        int y1 = y, c1 = cx;
+        advance(y1, c1);
+        fetch(min(y1, h - 1), c1, db);
+        process(da, y, cx);
+        int y2 = y1, c2 = c1;
+        advance(y2, c2);
+        fetch(min(y2, h - 1), c2, da);
+        if (i + 1 < n_ch) process(db, y1, c1);
+        y = y2; cx = c2;
     }
-    // pixels beyond w (n < 32) matched the tables on zero bytes: clear them, the consumer ignores them anyway
-    const uint32_t keep = n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
-    for (int r = 0; r < b.n; r++) dst[((size_t)r * h + y) * words + j] = out[r] & keep;
 }
 
 hipError_t launch_in_range_bits(const u8 *src, size_t sstride, uint32_t *dst, int w, int h, const Bounds &b, hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return hipSuccess;
     const int words = (w + 31) / 32;
-    const int align = ((uintptr_t)src % 16 == 0 && sstride % 16 == 0) ? 16 : ((uintptr_t)src % 4 == 0 && sstride % 4 == 0) ? 4 : 1;
-    dim3 block(64, 4), grid((words + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(k_in_range_bits, grid, block, 0, stream, src, sstride, dst, words, w, h, b, align);
+    const bool fast = (uintptr_t)src % 4 == 0 && sstride % 4 == 0 && w % 4 == 0;
+    const int cpr = (w + 255) / 256;
+    const long long total = (long long)cpr * h;
+    if (total > 0x7FFFFFFFLL / 4 || (long long)words * h > 0x7FFFFFFFLL || (long long)w * 3 > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    // runs of chunks per wave: long enough to pay for the 3 KB of tables a workgroup builds, short enough for >= ~2000 workgroups
+    long long cpw = total / (4 * 2048);
+    cpw = cpw < 1 ? 1 : cpw > 16 ? 16 : cpw;
+    const long long waves = (total + cpw - 1) / cpw;
+    dim3 block(256), grid((unsigned)((waves + 3) / 4));
+    if (fast)
+        hipLaunchKernelGGL(k_in_range_bits<true>, grid, block, 0, stream, src, sstride, dst, words, w, h, b, cpr, (int)cpw, (int)total);
+    else
+        hipLaunchKernelGGL(k_in_range_bits<false>, grid, block, 0, stream, src, sstride, dst, words, w, h, b, cpr, (int)cpw, (int)total);
     return hipGetLastError();
 }
 
