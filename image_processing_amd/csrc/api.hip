@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -388,8 +389,13 @@ int alloc_slot(imgproc_ctx *c, Slot &s, bool staging = true)
 // Stage-by-stage chain for one frame whose raw bytes are at d_frame (device).  Final masks land in
 // d_masks_out (n_ranges planes of w*h, tight), moments are ADDED into d_mom (caller zeroes).
 // `upto` < IMGPROC_STAGE_MASK stops after that stage (imgproc_fetch_stage rebuilding a stage image on demand).
+// `bits_out` (only when bit_plane_tail(plan) holds): the frame's inRange bit planes go there and the morphology is left
+// to the caller, who runs it for several frames in one launch.
+static bool bit_plane_tail(const Plan &p) { return p.bm_ok && !p.pipe.force_unfused && !p.pipe.keep_stages; }
+
 int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, int w, int h, u8 *d_masks_out,
-                unsigned long long *d_mom, int *launches, hipStream_t st, int upto = IMGPROC_STAGE_MASK)
+                unsigned long long *d_mom, int *launches, hipStream_t st, int upto = IMGPROC_STAGE_MASK,
+                uint32_t *bits_out = nullptr)
 {
     const Plan &p = c->plan;
     const size_t t3 = (size_t)w * 3, px = (size_t)w * h;
@@ -428,11 +434,15 @@ int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, i
     if (upto == IMGPROC_STAGE_BLUR) return 0;
     const int nr = p.bounds.n;
     const bool to_bitmorph = p.bm_ok && !p.pipe.force_unfused;
-    if (to_bitmorph && upto > IMGPROC_STAGE_THRESH && !p.pipe.keep_stages) {
+    if (bit_plane_tail(p) && upto > IMGPROC_STAGE_THRESH) {
         // nobody asked for the inRange bytes: the planes go to the bit-plane morphology as bits (1/8 B per px and range),
         // then the whole morph list + moments + final masks for all ranges in one launch
-        uint32_t *bits = reinterpret_cast<uint32_t *>(s.d_thresh);
+        uint32_t *bits = bits_out ? bits_out : reinterpret_cast<uint32_t *>(s.d_thresh);
         HIPCHK(c, ipk::launch_in_range_bits(blur, t3, bits, w, h, p.bounds, st));
+        if (bits_out) {
+            if (launches) *launches += nl + 1;
+            return 0;
+        }
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, nullptr, d_masks_out, d_mom, w, h, nr, p.pipe.second_order, st, bits));
         if (launches) *launches += nl + 2;
         return 0;
@@ -1011,6 +1021,34 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, c->d_thresh_batch, (u8 *)d_masks, bt.d_mom, w, h, n * nr,
                                        p.pipe.second_order, c->stream, bits));
         bt.launches = 2;
+    } else if (bit_plane_tail(p)) {
+        // stage kernels per frame up to the inRange bit planes, then the bit-plane morphology of a whole group of frames in
+        // one launch (planes = frames x ranges): at one 8K frame it has too few independent columns to fill the chip
+        const size_t per_frame = (size_t)nr * h * ipm::bit_words(w) * 4;
+        const size_t cap = (size_t)1 << 30;  // at most 1 GiB of bit planes at a time
+        const int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap / std::max<size_t>(per_frame, 1)));
+        const size_t need = per_frame * group;
+        if (need > c->thresh_batch_bytes) {  // grown on demand, kept for the life of the context
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // the other ticket may still be using the old buffer
+            if (c->d_thresh_batch) HIPCHK(c, hipFree(c->d_thresh_batch));
+            c->d_thresh_batch = nullptr;
+            c->thresh_batch_bytes = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_thresh_batch, need));
+            c->thresh_batch_bytes = need;
+        }
+        uint32_t *bits = reinterpret_cast<uint32_t *>(c->d_thresh_batch);
+        for (int g0 = 0; g0 < n; g0 += group) {
+            const int gn = std::min(group, n - g0);
+            for (int i = 0; i < gn; i++) {
+                rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)(g0 + i) * frame_stride, row_stride, w, h, nullptr, nullptr,
+                                 &bt.launches, c->stream, IMGPROC_STAGE_MASK, bits + (size_t)i * (per_frame / 4));
+                if (rc) return rc;
+            }
+            u8 *mout = d_masks ? (u8 *)d_masks + (size_t)g0 * nr * px : nullptr;  // no mask buffer: moments only
+            HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, nullptr, mout, bt.d_mom + (size_t)g0 * nr * 6, w, h, gn * nr,
+                                           p.pipe.second_order, c->stream, bits));
+            bt.launches++;
+        }
     } else {
         for (int i = 0; i < n; i++) {
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;

@@ -392,8 +392,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 // stays with k_bitmorph.  ~24 VALU per group and 32-px word, against ~25 per word, group AND halo-inflated tile word
 // (x1.8 for polygon_path) plus index arithmetic there.
 // ---------------------------------------------------------------------------------------------
-struct WinC {  // one merged RECT window, as the planner's Group / Span holds it
+struct SpanC {  // one distinct row span of a non-RECT element, as the planner's Span: bit i of rows = element row dlo + i
+    int lx, hx, dlo;
+    unsigned rows;
+};
+struct WinC {  // one group as the planner holds it: a merged RECT window (nsp == 0), or an element's spans inside the box
     int kind, lx, hx, dlo, dhi;
+    int nsp;
+    SpanC sp[3];
 };
 struct ListPolygonPath {
     static constexpr int NG = 5;
@@ -408,6 +414,18 @@ struct ListPoseEstimate {
     static constexpr WinC get(int g)
     {
         constexpr WinC t[NG] = {{0, -2, 2, -2, 2}, {1, -8, 6, -8, 6}, {0, -2, 2, -2, 2}};
+        return t[g];
+    }
+};
+
+// the stress preset's list (BASELINE configs[4]): erode, then dilate with getStructuringElement(MORPH_ELLIPSE, 9x9):
+// rows of 1, 7, 7, 9, 9, 9, 7, 7, 1 pixels
+struct ListOpenEllipse9 {
+    static constexpr int NG = 2;
+    static constexpr WinC get(int g)
+    {
+        constexpr WinC t[NG] = {{0, -4, 4, -4, 4, 3, {{0, 0, -4, 0x101u}, {-3, 3, -3, 0x63u}, {-4, 4, -1, 0x7u}}},
+                                {1, -4, 4, -4, 4, 3, {{0, 0, -4, 0x101u}, {-3, 3, -3, 0x63u}, {-4, 4, -1, 0x7u}}}};
         return t[g];
     }
 };
@@ -428,6 +446,32 @@ struct StripArgs {
 };
 
 constexpr int bs_pow2_le(int v) { return v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1; }
+constexpr bool bs_uses_lds(const WinC &w)  // a RECT window whose last vertical combine reaches more than 2 rows back
+{
+    const int H = w.dhi - w.dlo + 1;
+    return w.nsp == 0 && (H - bs_pow2_le(H)) > 2;
+}
+
+// AND of the bits x+LX .. x+HX of a row (x = this lane's word, L / R = its neighbours' words; ones beyond the string)
+template <int LX, int HX>
+__device__ __forceinline__ uint32_t bs_hwindow(uint32_t x, uint32_t L, uint32_t R)
+{
+    static_assert(LX <= 0 && LX >= -31 && HX >= LX && HX - LX < 33, "window offsets");
+    constexpr int ex = 32 + LX, len = HX - LX + 1;
+    uint32_t b0 = x, b1 = R;
+    if (ex != 32) {
+        b0 = funnel(x, L, ex);
+        b1 = funnel(R, x, ex);
+    }
+    if (len >= 2) { b0 &= funnel(b1, b0, 1); if (len > 2) b1 &= funnel(0xFFFFFFFFu, b1, 1); }
+    if (len >= 4) { b0 &= funnel(b1, b0, 2); if (len > 4) b1 &= funnel(0xFFFFFFFFu, b1, 2); }
+    if (len >= 8) { b0 &= funnel(b1, b0, 4); if (len > 8) b1 &= funnel(0xFFFFFFFFu, b1, 4); }
+    if (len >= 16) { b0 &= funnel(b1, b0, 8); if (len > 16) b1 &= funnel(0xFFFFFFFFu, b1, 8); }
+    if (len >= 32) { b0 &= funnel(b1, b0, 16); if (len > 32) b1 &= funnel(0xFFFFFFFFu, b1, 16); }
+    constexpr int have = len >= 32 ? 32 : len >= 16 ? 16 : len >= 8 ? 8 : len >= 4 ? 4 : len >= 2 ? 2 : 1;
+    if (have < len) b0 &= funnel(b1, b0, len - have);  // the window is two overlapping runs of `have` bits
+    return b0;
+}
 
 template <class LIST, bool M2>
 __global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
@@ -436,7 +480,7 @@ __global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
     // per group: window height, doubling level, distance of the last combine; which groups keep that ring in LDS
     constexpr int HT = [] { int s = 0; for (int g = 0; g < NG; g++) s += -LIST::get(g).dlo; return s; }();
     constexpr int HB = [] { int s = 0; for (int g = 0; g < NG; g++) s += LIST::get(g).dhi; return s; }();
-    constexpr int N_LDS = [] { int n = 0; for (int g = 0; g < NG; g++) { const int H = LIST::get(g).dhi - LIST::get(g).dlo + 1; n += (H - bs_pow2_le(H)) > 2; } return n; }();
+    constexpr int N_LDS = [] { int n = 0; for (int g = 0; g < NG; g++) n += bs_uses_lds(LIST::get(g)); return n; }();
     static_assert(N_LDS >= 0 && N_LDS <= NG, "ring count");
     __shared__ uint32_t s_ring[4][N_LDS > 0 ? N_LDS : 1][8][64];  // per wave: the last 8 rows of a group's level-P results
     __shared__ uint32_t s_lut[16];                                // nibble -> four 0/255 bytes
@@ -463,11 +507,14 @@ __global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
     u8 *mrow = a.masks ? a.masks + (size_t)plane * w * h : nullptr;  // uniform
 
     uint32_t prev1[NG], ring2[NG][2], ring4[NG][4], ringp[NG][2];
+    uint32_t ringe[NG][3][8];  // non-RECT groups: the last 8 rows of every span's horizontal window (slots = register names)
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         prev1[g] = ring2[g][0] = ring2[g][1] = ringp[g][0] = ringp[g][1] = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < 4; q++) ring4[g][q] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 24; q++) ringe[g][q >> 3][q & 7] = 0xFFFFFFFFu;
     }
     uint32_t m00 = 0, m01 = 0, bsa[5] = {0, 0, 0, 0, 0};  // first-order sums of this lane's word column (u32: <= 512 rows)
     unsigned long long m20 = 0, m11 = 0, m02 = 0;
@@ -494,51 +541,61 @@ __global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
             auto group = [&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 constexpr WinC W = LIST::get(g);
-                constexpr int ex = 32 + W.lx, len = W.hx - W.lx + 1;
                 constexpr int H = W.dhi - W.dlo + 1, P = bs_pow2_le(H), dist = H - P;
                 // rows of reach below summed over groups 0..g, and the LDS ring this group uses (if any)
                 constexpr int below = [] { int b = 0; for (int q = 0; q <= g; q++) b += LIST::get(q).dhi; return b; }();
-                constexpr int lds_i = [] { int n = 0; for (int q = 0; q < g; q++) { const int h2 = LIST::get(q).dhi - LIST::get(q).dlo + 1; n += (h2 - bs_pow2_le(h2)) > 2; } return n; }();
-                // ---- horizontal: AND of bits x+lx .. x+hx ----
+                constexpr int lds_i = [] { int n = 0; for (int q = 0; q < g; q++) n += bs_uses_lds(LIST::get(q)); return n; }();
                 const uint32_t R = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x130, 0xF, 0xF, true);  // lane+1 (lane 63: 0, halo)
-                uint32_t b0 = x, b1 = R;
-                if (ex != 32) {
-                    const uint32_t L = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xF, 0xF, true);  // lane-1
-                    b0 = funnel(x, L, ex);
-                    b1 = funnel(R, x, ex);
-                }
-                if (len >= 2) { b0 &= funnel(b1, b0, 1); if (len > 2) b1 &= funnel(0xFFFFFFFFu, b1, 1); }
-                if (len >= 4) { b0 &= funnel(b1, b0, 2); if (len > 4) b1 &= funnel(0xFFFFFFFFu, b1, 2); }
-                if (len >= 8) { b0 &= funnel(b1, b0, 4); if (len > 8) b1 &= funnel(0xFFFFFFFFu, b1, 4); }
-                if (len >= 16) { b0 &= funnel(b1, b0, 8); if (len > 16) b1 &= funnel(0xFFFFFFFFu, b1, 8); }
-                if (len >= 32) { b0 &= funnel(b1, b0, 16); if (len > 32) b1 &= funnel(0xFFFFFFFFu, b1, 16); }
-                constexpr int have = len >= 32 ? 32 : len >= 16 ? 16 : len >= 8 ? 8 : len >= 4 ? 4 : len >= 2 ? 2 : 1;
-                if (have < len) b0 &= funnel(b1, b0, len - have);  // the window is two overlapping runs of `have` bits
-                // ---- vertical: AND of this and the previous height-1 rows of b0 ----
-                uint32_t out = b0;
-                if (P >= 2) {
-                    out = b0 & prev1[g];
-                    prev1[g] = b0;
-                }
-                if (P >= 4) {
-                    const uint32_t p2 = out;
-                    out = p2 & ring2[g][u & 1];
-                    ring2[g][u & 1] = p2;
-                }
-                if (P >= 8) {
-                    const uint32_t p4 = out;
-                    out = p4 & ring4[g][u & 3];
-                    ring4[g][u & 3] = p4;
-                }
-                if (dist > 2) {  // the level-P value of `dist` rows ago: LDS ring, constant slots
-                    ring[lds_i][u][lane] = out;
-                    __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering
-                    out &= ring[lds_i][(u - dist) & 7][lane];
-                    __builtin_amdgcn_wave_barrier();
-                } else if (dist > 0) {  // 1 or 2 rows ago: two registers
-                    const uint32_t pp = out;
-                    out = pp & ringp[g][(u - dist) & 1];
-                    ringp[g][u & 1] = pp;
+                const uint32_t L = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xF, 0xF, true);  // lane-1
+                uint32_t out;
+                if constexpr (W.nsp == 0) {
+                    // ---- horizontal: AND of bits x+lx .. x+hx ----
+                    const uint32_t b0 = bs_hwindow<W.lx, W.hx>(x, L, R);
+                    // ---- vertical: AND of this and the previous height-1 rows of b0 ----
+                    out = b0;
+                    if (P >= 2) {
+                        out = b0 & prev1[g];
+                        prev1[g] = b0;
+                    }
+                    if (P >= 4) {
+                        const uint32_t p2 = out;
+                        out = p2 & ring2[g][u & 1];
+                        ring2[g][u & 1] = p2;
+                    }
+                    if (P >= 8) {
+                        const uint32_t p4 = out;
+                        out = p4 & ring4[g][u & 3];
+                        ring4[g][u & 3] = p4;
+                    }
+                    if (dist > 2) {  // the level-P value of `dist` rows ago: LDS ring, constant slots
+                        ring[lds_i][u][lane] = out;
+                        __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering
+                        out &= ring[lds_i][(u - dist) & 7][lane];
+                        __builtin_amdgcn_wave_barrier();
+                    } else if (dist > 0) {  // 1 or 2 rows ago: two registers
+                        const uint32_t pp = out;
+                        out = pp & ringp[g][(u - dist) & 1];
+                        ringp[g][u & 1] = pp;
+                    }
+                } else {
+                    // ---- an element of row spans (ELLIPSE / CROSS): every distinct span's horizontal window of this row,
+                    // kept for 8 rows; the output row is the AND over the element's rows of the window each one uses, `age`
+                    // rows ago (the row that just came in is the element's bottom row) ----
+                    static_assert(H <= 9, "the span rings hold 8 rows");
+                    out = 0xFFFFFFFFu;
+                    auto span = [&](auto sc) {
+                        constexpr int si = decltype(sc)::value;
+                        constexpr SpanC S = W.sp[si];
+                        const uint32_t hv = bs_hwindow<S.lx, S.hx>(x, L, R);
+#pragma unroll
+                        for (int i = 0; i < 9; i++) {
+                            if (!((S.rows >> i) & 1u)) continue;
+                            const int age = W.dhi - (S.dlo + i);
+                            out &= age == 0 ? hv : ringe[g][si][(u - age) & 7];  // age 8: the slot about to be replaced
+                        }
+                        ringe[g][si][u & 7] = hv;
+                    };
+                    bs_for_each(span, std::make_integer_sequence<int, W.nsp>{});
                 }
                 // ---- into the next group's erode domain; its rows outside the image are neutral ----
                 if (g + 1 < NG) {
@@ -572,15 +629,17 @@ __global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
                     const int xs = (strip * a.valid_words - a.hwl + sl) * 32 + 16 * (lane & 1);  // first pixel of this lane's piece
                     const bool src_writer = sl >= a.hwl && sl < a.hwl + a.valid_words;
                     const int nd = src_writer && xs >= 0 ? min(4, (w - xs) >> 2) : 0;  // dwords inside the row (w % 4 == 0)
-                    if (nd > 0) {
-                        uint32_t *o32 = reinterpret_cast<uint32_t *>(mrow + (size_t)y * w + xs);
-                        if (nd == 4) {
-                            *reinterpret_cast<uint4 *>(o32) = make_uint4(o[0], o[1], o[2], o[3]);
-                        } else {
+                    uint32_t *o32 = reinterpret_cast<uint32_t *>(mrow + (size_t)y * w + xs);
+                    if ((w & 15) == 0) {  // uniform; a lane's 16 bytes are inside the row or outside.  Kept apart from the
+                        // general case: with both in one if / else the compiler hoists the store of o[0] out of them and
+                        // the 16-byte store becomes a 4-byte and a 12-byte one
+                        if (nd == 4) *reinterpret_cast<uint4 *>(o32) = make_uint4(o[0], o[1], o[2], o[3]);
+                    } else if (nd == 4) {
+                        *reinterpret_cast<uint4 *>(o32) = make_uint4(o[0], o[1], o[2], o[3]);
+                    } else {
 #pragma unroll
-                            for (int q = 0; q < 3; q++)
-                                if (q < nd) o32[q] = o[q];
-                        }
+                        for (int q = 0; q < 3; q++)
+                            if (q < nd) o32[q] = o[q];
                     }
                 }
             }
@@ -735,14 +794,27 @@ template <class LIST>
 static bool strip_matches(const Plan &plan)
 {
     if ((int)plan.groups.size() != LIST::NG || plan.hwl > 1 || plan.hwr > 1) return false;
+    int ht = 0, hb = 0;
     for (int g = 0; g < LIST::NG; g++) {
         const Group &G = plan.groups[g];
-        if (G.n_spans != 1 || G.spans[0].rows != 0) return false;
-        const Span &sp = G.spans[0];
         const WinC c = LIST::get(g);
-        if (G.kind != c.kind || sp.lx != c.lx || sp.hx != c.hx || sp.dy_lo != c.dlo || sp.dy_hi != c.dhi) return false;
+        if (G.kind != c.kind) return false;
+        ht += -c.dlo;
+        hb += c.dhi;
+        if (c.nsp == 0) {  // a (merged) RECT window
+            if (G.n_spans != 1 || G.spans[0].rows != 0) return false;
+            const Span &sp = G.spans[0];
+            if (sp.lx != c.lx || sp.hx != c.hx || sp.dy_lo != c.dlo || sp.dy_hi != c.dhi) return false;
+        } else {  // an element of row spans: the same spans on the same rows, in the planner's order (first appearance)
+            if (G.n_spans != c.nsp) return false;
+            for (int i = 0; i < c.nsp; i++) {
+                const Span &sp = G.spans[i];
+                if (sp.lx != c.sp[i].lx || sp.hx != c.sp[i].hx || sp.dy_lo != c.sp[i].dlo || sp.rows != c.sp[i].rows) return false;
+                if (sp.dy_lo < c.dlo || sp.dy_hi > c.dhi) return false;
+            }
+        }
     }
-    return true;
+    return ht == plan.ht && hb == plan.hb;  // the kernel's reach is the planner's (elements with empty border rows differ)
 }
 
 static int g_bs_seg_rows = -1, g_bs_mode = -1;  // IMGPROC_BITSTRIP: 0 never, 1 when the job is large (default), 2 whenever the list matches
@@ -766,7 +838,7 @@ static hipError_t launch_bitstrip(const Plan &plan, const uint32_t *d_tbits, u8 
     const long long cols = (long long)planes * a.n_strips;
     int seg = g_bs_seg_rows > 0 ? g_bs_seg_rows : (int)((long long)h * cols / 4096);
     if (g_bs_seg_rows <= 0 && seg < reach + reach / 2) seg = reach + reach / 2;
-    seg = seg < 48 ? 48 : seg > 512 ? 512 : seg;
+    seg = seg < (g_bs_seg_rows > 0 ? 8 : 48) ? (g_bs_seg_rows > 0 ? 8 : 48) : seg > 512 ? 512 : seg;
     a.n_segs = (h + seg - 1) / seg;
     a.seg_rows = (h + a.n_segs - 1) / a.n_segs;
     const long long items = cols * a.n_segs;
@@ -799,6 +871,8 @@ hipError_t launch_bitmorph(const Plan &plan, const Group *d_groups, const u8 *d_
             return launch_bitstrip<ListPolygonPath>(plan, d_tbits, d_masks, d_mom, w, h, planes, second_order, stream);
         if (strip_matches<ListPoseEstimate>(plan))
             return launch_bitstrip<ListPoseEstimate>(plan, d_tbits, d_masks, d_mom, w, h, planes, second_order, stream);
+        if (strip_matches<ListOpenEllipse9>(plan))
+            return launch_bitstrip<ListOpenEllipse9>(plan, d_tbits, d_masks, d_mom, w, h, planes, second_order, stream);
     }
     Args a{};
     a.thresh = d_tbits ? nullptr : d_thresh;

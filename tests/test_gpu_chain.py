@@ -494,16 +494,22 @@ def test_up_to_eight_ranges_in_one_launch(gpu, oracle, nr, preset):
         check_moments(res1[r], exp["moments"][r], second=True)
 
 
-@pytest.mark.parametrize("preset", ["polygon_path", "pose_estimate_full"])
+STRIP_PRESETS = dict(PRESETS)
+# BASELINE configs[4]'s operators: the strip kernel's instantiation for an element of row spans (9x9 ellipse open)
+STRIP_PRESETS["stress"] = dict(pre_blur_k=0, post_blur_k=15, morph=[ip.E(9, L.ELLIPSE), ip.D(9, L.ELLIPSE)])
+
+
+@pytest.mark.parametrize("preset", ["polygon_path", "pose_estimate_full", "stress"])
 @pytest.mark.parametrize("hw", [(4, 8), (37, 64), (100, 252), (123, 516), (300, 1920), (211, 2100), (96, 4096)])
 @pytest.mark.parametrize("seg_rows", [0, 48])
 def test_bit_plane_strip_kernel(gpu, oracle, monkeypatch, preset, hw, seg_rows):
-    """The strip form of the bit-plane morphology (instantiated for the two morphOps lists of the reference; normally
-    taken only for large jobs) forced on small and wide frames: one strip and several, several segments per plane, words
-    cut by the right edge; equal to the oracle and to the tile kernel, second-order sums included."""
+    """The strip form of the bit-plane morphology (instantiated for the two morphOps lists of the reference and for the
+    stress preset's elliptical open; normally taken only for large jobs) forced on small and wide frames: one strip and
+    several, several segments per plane, words cut by the right edge; equal to the oracle and to the tile kernel,
+    second-order sums included."""
     h, w = hw
     n = 2
-    kw = PRESETS[preset]
+    kw = STRIP_PRESETS[preset]
     frames = np.random.default_rng(h + w).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     frames[:, h // 5: h - h // 6, w // 7: w - w // 5] //= 3  # a large dark region: something survives the erosions
     ranges = [((0, 0, 0), (256, 256, 110)), DEFAULT_RANGE]
