@@ -611,13 +611,14 @@ __global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
             const bool row_out = y >= ys && y < ye;  // uniform: the pipeline is still filling / past the segment
             const uint32_t bits = row_out ? (x ^ km_last) & ~cinv : 0u;
             if (a.masks && row_out) {
-                // Bytes out, each store instruction one contiguous KB per wave: lane l takes the 16 pixels
-                // [16 l, 16 l + 16) of the strip's first (second) 1024 from lane l/2 (32 + l/2) through the LDS crossbar
-                // (a lane storing its own 32 bytes would leave every 64-byte line to two instructions).
+                // Bytes out, each store instruction one contiguous KB per wave, starting at the strip's first owned word
+                // (whole 128-byte lines when the row pitch allows): lane l takes the 16 pixels [16 l, 16 l + 16) of the
+                // strip's first (second) 1024 from lane hwl + l/2 (hwl + 32 + l/2) through the LDS crossbar (a lane
+                // storing its own 32 bytes would leave every 64-byte line to two instructions).
                 const uint32_t wbits = writer ? bits : 0u;
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
-                    const int sl = 32 * half + (lane >> 1);  // source lane = word of the strip
+                    const int sl = a.hwl + 32 * half + (lane >> 1);  // source lane = word of the strip (64: none)
                     const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(sl * 4, (int)wbits);
                     const uint32_t b16 = (lane & 1) ? word >> 16 : word;
                     uint32_t o[4];
@@ -830,7 +831,8 @@ static hipError_t launch_bitstrip(const Plan &plan, const uint32_t *d_tbits, u8 
     a.mom = d_mom;
     a.w = w; a.h = h; a.planes = planes;
     a.hwl = plan.hwl;
-    a.valid_words = a.twords <= 64 - plan.hwl - plan.hwr ? a.twords : 64 - plan.hwl - plan.hwr;
+    // several strips: a multiple of 4 words each, so that strips start on 128-byte lines
+    a.valid_words = a.twords <= 64 - plan.hwl - plan.hwr ? a.twords : ((64 - plan.hwl - plan.hwr) & ~3);
     a.n_strips = (a.twords + a.valid_words - 1) / a.valid_words;
     // Segments: every segment re-runs the list's rows of reach, so they should be long; the chip wants a few thousand
     // waves.  ~4000 waves when the job has them, at least 1.5 x the reach and 48 rows, at most 512 (u32 sums per lane).

@@ -1,0 +1,53 @@
+"""Rebuilds profiles/r02_pmc_summary.json (what bench.py quotes as offline traffic / VALU figures) from the per-configuration
+counter files profiles/r02_<config>_counters.json that scripts/prof_config.sh + scripts/pmc_collect.py produce.
+usage: python3 scripts/pmc_merge.py            (reads and writes under profiles/)"""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+WHAT = ("Per configuration of bench.py: HBM bytes and VALU instructions of one batch's chain kernel(s), from the rocprofv3 passes "
+        "in profiles/r02_<config>_counters.json (scripts/prof_config.sh: kernel-trace stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE and "
+        "two SQ groups, each a run of its own; merged by scripts/pmc_merge.py). hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE for kernels "
+        "whose loads the guide's gfx950 rule covers or that were calibrated here (k_fused_chain, k_bgr2hsv, k_gaussian_*, "
+        "k_in_range_bits: 2 x FETCH_SIZE reproduces their known input bytes x halo); k_bitmorph's / k_bitstrip's dword loads of bit "
+        "planes are counted as reported (FETCH_SIZE x 1: that already equals bit-plane bytes x tile overlap). bench.py quotes these "
+        "as offline figures (traffic_source).")
+FETCH_X1 = ("k_bitmorph", "k_bitstrip")  # FETCH_SIZE already in units of 1 KB of HBM reads for these
+
+
+def main():
+    out = {"_what": WHAT}
+    for cfg in ("c2", "c3", "pp", "c5", "pe"):
+        path = os.path.join(PROF, "r02_%s_counters.json" % cfg)
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        line = d["bench_line_under_rocprof"]
+        frames = line["config"]["frames_per_batch"]
+        steps = line["steps"] + line["warmup"]
+        kernels, hbm, valu = {}, 0.0, 0.0
+        total_calls = sum(k["calls"] for k in d["kernels"].values())
+        launches = line["roofline"].get("launches_per_batch") or len(d["kernels"])
+        for name, k in d["kernels"].items():
+            if "FETCH_SIZE" not in k or "SQ_INSTS_VALU" not in k:
+                continue
+            per_batch = max(1, round(launches * k["calls"] / total_calls))  # this kernel's share of a batch's launches
+            fx = 1.0 if any(s in name for s in FETCH_X1) else 2.0
+            rd, wr = fx * k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
+            cyc = k["avg_ns"] * 2.4 * 1024.0 / k["SQ_INSTS_VALU"]  # SIMD cycles at 2.4 GHz per VALU instruction
+            kernels[name] = {"launches_per_batch": per_batch, "avg_us": k["avg_ns"] / 1e3, "read_bytes": rd, "write_bytes": wr,
+                             "valu_insts": k["SQ_INSTS_VALU"], "salu_insts": k.get("SQ_INSTS_SALU"), "lds_insts": k.get("SQ_INSTS_LDS"),
+                             "waves": k.get("SQ_WAVES"), "valu_cycles_per_inst_at_2.4GHz": cyc}
+            hbm += per_batch * (rd + wr)
+            valu += per_batch * k["SQ_INSTS_VALU"]
+        out[cfg] = {"frames_per_launch": frames, "hbm_bytes_per_launch": hbm, "valu_insts_per_launch": valu,
+                    "lib_sha16": d.get("lib_sha16"), "kernels": kernels}
+    json.dump(out, open(os.path.join(PROF, "r02_pmc_summary.json"), "w"), indent=1)
+    for cfg, v in out.items():
+        if cfg != "_what":
+            print(cfg, "%.3f GB, %.1f M VALU per batch of %d" % (v["hbm_bytes_per_launch"] / 1e9, v["valu_insts_per_launch"] / 1e6, v["frames_per_launch"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,31 @@ __global__ __launch_bounds__(256) void k_rows(unsigned char *dst, int w, int h, 
     }
 }
 
+// rows + K dependent VALU ops per row and half (does the store stream overlap with a wave's own arithmetic?)
+template <bool STORE>
+__global__ __launch_bounds__(256) void k_rows_valu(unsigned char *dst, int w, int h, int planes, int seg_rows, int strips, int K, uint32_t *sink)
+{
+    const int lane = threadIdx.x & 63;
+    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = item % strips; item /= strips;
+    const int n_segs = (h + seg_rows - 1) / seg_rows;
+    const int seg = item % n_segs, plane = item / n_segs;
+    if (plane >= planes) return;
+    uint32_t acc = lane * 2654435761u;
+    for (int y = seg * seg_rows; y < min(h, (seg + 1) * seg_rows); y++) {
+        unsigned char *row = dst + ((size_t)plane * h + y) * w + strip * 2048;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            for (int k = 0; k < K; k++) acc = __builtin_amdgcn_alignbit(acc, acc ^ (uint32_t)y, 7) + 0x9E3779B9u;
+            const int x = strip * 2048 + half * 1024 + lane * 16;
+            if (STORE) {
+                if (x < w) *reinterpret_cast<uint4 *>(row + half * 1024 + lane * 16) = make_uint4(acc, acc + 1, acc + 2, acc + 3);
+            }
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main()
 {
     hipEvent_t e0, e1;
@@ -86,6 +111,21 @@ int main()
             char nm[64];
             snprintf(nm, sizeof nm, "rows, %d rows per wave", seg);
             time(nm, [&] { hipLaunchKernelGGL(k_rows, dim3((items + 3) / 4), dim3(256), 0, 0, d, w, h, planes, seg, strips); });
+        }
+        if (planes == 32) {
+            uint32_t *sink;
+            hipMalloc(&sink, 64);
+            for (int K : {0, 16, 32, 64, 128}) {
+                const int seg = 135;
+                const int strips = (w + 2047) / 2048, n_segs = (h + seg - 1) / seg;
+                const int items = strips * n_segs * planes;
+                char nm[64];
+                snprintf(nm, sizeof nm, "rows+%d valu per half, store", 2 * K);
+                time(nm, [&] { hipLaunchKernelGGL(k_rows_valu<true>, dim3((items + 3) / 4), dim3(256), 0, 0, d, w, h, planes, seg, strips, K, sink); });
+                snprintf(nm, sizeof nm, "rows+%d valu per half, none", 2 * K);
+                time(nm, [&] { hipLaunchKernelGGL(k_rows_valu<false>, dim3((items + 3) / 4), dim3(256), 0, 0, d, w, h, planes, seg, strips, K, sink); });
+            }
+            hipFree(sink);
         }
         hipFree(d);
     }
