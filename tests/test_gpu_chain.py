@@ -228,6 +228,43 @@ def test_stress_pipeline_small(gpu, oracle):
     assert sum(int(exp["moments"][r][0] > 0) for r in range(8)) >= 4
 
 
+@pytest.mark.parametrize("hw", [(50, 37), (33, 259), (40, 1022), (64, 260), (21, 2052)])
+def test_stress_operators_ragged_batches(oracle, hw):
+    """The stage path's bit-plane tail (inRange planes as bits, morphology once per group of frames) at widths that are no
+    multiple of 4 (byte loads in the inRange kernel, tile kernel behind it), a multiple of 4 but not of 16 or 32, and with a
+    padded row pitch; batches of 3 frames, with and without a mask buffer; 3 and 8 ranges."""
+    h, w = hw
+    n = 3
+    pitch = w * 3 + 20
+    rng = np.random.default_rng(h * w)
+    buf = rng.integers(0, 256, (n, h, pitch), dtype=np.uint8)
+    buf[:, h // 4: h - h // 4, (w // 5) * 3: (w - w // 5) * 3] //= 2
+    frames = np.ascontiguousarray(buf[:, :, : w * 3].reshape(n, h, w, 3))
+    morph = [ip.E(9, L.ELLIPSE), ip.D(9, L.ELLIPSE)]
+    for ranges in ([((0, 0, 0), (256, 256, 140)), ((10, 0, 0), (90, 200, 256)), ((256, 0, 0), (0, 256, 256))],
+                   [((20 * i, 0, 0), (20 * i + 30, 256, 200)) for i in range(8)]):
+        nr = len(ranges)
+        with ip.ImgProc(w, h, n_slots=1, max_batch=n) as g:
+            g.set_pipeline(post_blur_k=7, morph=morph)
+            g.set_ranges(ranges)
+            d_in, d_out = g.dev_alloc(buf.nbytes), g.dev_alloc(n * nr * w * h)
+            try:
+                g.dev_upload(d_in, buf)
+                res = g.process_batch_device(d_in, h * pitch, pitch, w, h, n, d_out)
+                masks = g.dev_download(d_out, (n, nr, h, w))
+                res_nomask = g.process_batch_device(d_in, h * pitch, pitch, w, h, n, None)
+            finally:
+                g.dev_free(d_in)
+                g.dev_free(d_out)
+        assert res == res_nomask
+        for i in range(n):
+            exp = oracle.chain(frames[i], post_blur_k=7, morph=morph_tuples(morph), ranges=ranges, stages=False)
+            for r in range(nr):
+                assert (masks[i, r] == exp["mask"][r]).all(), (hw, i, r)
+                check_moments(res[i][r], exp["moments"][r])
+        assert sum(int(m[0]) for m in exp["moments"]) > 0
+
+
 def test_process_batch_host(gpu, oracle):
     frames = synth_batch(160, 120, 7)
     p = PRESETS["baseline"]
