@@ -12,6 +12,9 @@ SOURCES = ["api.hip", "kernels.hip", "fused.hip", "fused_inst_plain_small.hip", 
            "fused_inst_bayer_small.hip", "fused_inst_bayer_large.hip", "morphbits.hip", "gauss.hip", "gauss_mfma.hip"]
 HEADERS = ["kernels.h", "fused.h", "fused_kernel.hpp", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread"]
+# per-source extras.  gauss_mfma.hip: MFMA results in VGPRs (the allocator's default put the accumulators into AGPRs and paid
+# 48 v_accvgpr_read per 16-row block, a quarter of the kernel's vector instructions, to get them back out)
+EXTRA_FLAGS = {"gauss_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 OBJDIR = os.path.join(LIBDIR, "obj")
@@ -37,7 +40,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [os.path.join(CSRC, src)] + headers):
-            jobs.append([hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", os.path.join(CSRC, src), "-o", obj])
+            jobs.append([hipcc] + [f for f in FLAGS if f != "-shared"] + EXTRA_FLAGS.get(src, []) +
+                        ["-c", os.path.join(CSRC, src), "-o", obj])
 
     def run(cmd):
         if verbose:

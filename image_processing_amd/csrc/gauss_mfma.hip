@@ -15,8 +15,8 @@
 // Input blocks are loaded coalesced (adjacent lanes = adjacent bytes, four rows per instruction) and turned into operand
 // order through a per-wave LDS tile: loading straight into operand order (adjacent lanes = adjacent ROWS) made every
 // lane its own memory request, 44 cycles per load instruction.  Workgroups are mapped XCD-aware (neighbouring strips
-// share input lines and meet in one L2).  Measured at 7680x4320x3, k = 15: 0.086 ms against 0.127 ms for the strip
-// kernel; what is left is ~250 vector instructions of addressing, packing and accumulator moves per 1024 output bytes.
+// share input lines and meet in one L2).  Measured at 7680x4320x3, k = 15: 0.074 ms against 0.127 ms for the strip
+// kernel.  Built with -amdgpu-mfma-vgpr-form (build.py): the accumulators stay in VGPRs, no v_accvgpr_read.
 // i8 operands are signed: every data byte is XORed with 0x80 (v - 128) and the constant term 128 * sum(taps) = 2^15 goes
 // into the accumulator's initial value; taps are <= 127 for k >= 5 (k = 3 has a 128 and stays with the strip kernel).
 // The arithmetic is OpenCV's: exact integer sums, one rounding (+2^15) >> 16; results are
@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ipk {
 
@@ -116,7 +117,18 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
     // row 4k + l / 14, so adjacent lanes read adjacent bytes (the MFMA operand layout -- adjacent lanes = adjacent ROWS --
     // made every lane its own memory request: 44 cycles per load instruction).  The block then goes through a per-wave
     // LDS tile and is read back in operand order.
-    const int lrow = lane / 14, lq = lane - 14 * lrow;  // lanes 56..63 idle in the loads
+    // The interior strips' loads are unconditional (lanes 56..63 repeat lane 55's; beyond the segment's end the last block
+    // is loaded again): a load behind a branch makes the compiler wait for ALL outstanding loads where the paths join --
+    // the two blocks "in flight" were being waited for right after they were issued.  The edge strips' byte path keeps
+    // its branches and runs as a second copy of the loop (EDGE), chosen per wave.
+    const int ll = min(lane, 55);
+    const int lrow = ll / 14, lq = ll - 14 * lrow;
+    uint2(*stage)[14] = s_stage[wv];  // [16 rows][14 chunks]
+    uint32_t(*mid)[2][4][GM_NT][16] = s_mid[wv];
+    uint32_t(*ost)[16] = s_out[wv];
+    const int Bs = seg * a.seg_blocks, Be = min(Bs + a.seg_blocks, a.nblocks);
+    auto run = [&](auto edge_c) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     auto load_block = [&](int blk, uint32_t (&ld)[4][2]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -124,37 +136,36 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
             const u8 *row = a.src + (uint32_t)y * (uint32_t)a.sstride;  // 32-bit offsets (image < 4 GB, checked at launch): saddr-form loads
             const int p = X - GM_OFF + 8 * lq;
             uint32_t v0 = 0, v1 = 0;
-            if (lane < 56) {
-                if (!edge_strip || (p >= 0 && p + 8 <= wb)) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(row + p);
-                    v0 = q[0];
-                    v1 = q[1];
-                } else {
-                    const int *o = offs + 8 * lq;
-                    uint32_t bb[8];
+            if (!EDGE) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(row + p);
+                v0 = q[0];
+                v1 = q[1];
+            } else if (p >= 0 && p + 8 <= wb) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(row + p);
+                v0 = q[0];
+                v1 = q[1];
+            } else {
+                const int *o = offs + 8 * lq;
+                uint32_t bb[8];
 #pragma unroll
-                    for (int m = 0; m < 8; m++) bb[m] = row[o[m]];
-                    v0 = bb[0] | (bb[1] << 8) | (bb[2] << 16) | (bb[3] << 24);
-                    v1 = bb[4] | (bb[5] << 8) | (bb[6] << 16) | (bb[7] << 24);
-                }
+                for (int m = 0; m < 8; m++) bb[m] = row[o[m]];
+                v0 = bb[0] | (bb[1] << 8) | (bb[2] << 16) | (bb[3] << 24);
+                v1 = bb[4] | (bb[5] << 8) | (bb[6] << 16) | (bb[7] << 24);
             }
-            ld[k][0] = v0 ^ 0x80808080u;
-            ld[k][1] = v1 ^ 0x80808080u;
+            ld[k][0] = v0;  // raw: the first use (and with it the wait for the load) is the LDS write two steps later
+            ld[k][1] = v1;
         }
     };
-    uint2(*stage)[14] = s_stage[wv];  // [16 rows][14 chunks]
-
-    uint32_t(*mid)[2][4][GM_NT][16] = s_mid[wv];
-    uint32_t(*ost)[16] = s_out[wv];
-    const int Bs = seg * a.seg_blocks, Be = min(Bs + a.seg_blocks, a.nblocks);
-    uint32_t nxt[4][2], nx2[4][2], cur[6][2];
-    load_block(Bs - 1, nxt);
-    load_block(Bs, nx2);
-    for (int blk = Bs - 1; blk <= Be; blk++) {
+    // Two register buffers take the blocks alternately (the loop is unrolled twice by hand, so no buffer is ever copied:
+    // a copy would be a use, and the wait for the load would move up to it).  A step writes its buffer to the LDS tile
+    // and refills it at once with the block two steps ahead.
+    uint32_t bufA[4][2], bufB[4][2];
+    auto step = [&](int blk, uint32_t (&buf)[4][2]) {
+        uint32_t cur[6][2];
         // this block through the LDS tile into operand order: lane (row i16, chunk c) takes chunks c + 2u, u = 0..5
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (lane < 56) stage[4 * k + lrow][lq] = make_uint2(nxt[k][0], nxt[k][1]);
+            if (lane < 56) stage[4 * k + lrow][lq] = make_uint2(buf[k][0] ^ 0x80808080u, buf[k][1] ^ 0x80808080u);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < 6; u++) {
@@ -163,9 +174,7 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
             cur[u][1] = v.y;
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 4; k++) nxt[k][0] = nx2[k][0], nxt[k][1] = nx2[k][1];
-        if (blk + 2 <= Be) load_block(blk + 2, nx2);  // two blocks in flight while this one is multiplied
+        load_block(min(blk + 2, Be), buf);  // two blocks in flight while this one is multiplied
         // ---- row pass of block blk, packed into the ring: all first halves, then all second halves, so that no MFMA
         // waits for the one just issued ----
         const int slot = (blk + 3) % 3;
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
             mid[slot][1][c][t][i16] = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
         }
         __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order; keep the compiler from reordering
-        if (blk < Bs + 1) continue;       // the column pass of block ob needs blocks ob - 1, ob, ob + 1
+        if (blk < Bs + 1) return;         // the column pass of block ob needs blocks ob - 1, ob, ob + 1
         // ---- column pass of output block ob: window rows 16 ob - 8 .. 16 ob + 23 = row groups 4 ob - 2 .. 4 ob + 5 ----
         const int ob = blk - 1;
         const int wg = 2 * c + 2;  // this lane's first row group, counted from block ob - 1
@@ -226,7 +235,20 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };  // step
+    load_block(Bs - 1, bufA);
+    load_block(Bs, bufB);
+    int blk = Bs - 1;
+    for (; blk + 1 <= Be; blk += 2) {  // whole pairs only: a conditional second step would hide its loads from the first's wait
+        step(blk, bufA);
+        step(blk + 1, bufB);
     }
+    if (blk <= Be) step(blk, bufA);
+    };  // run
+    if (edge_strip)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
 }
 
 }  // namespace
@@ -253,9 +275,10 @@ hipError_t launch_gaussian_mfma(const u8 *src, size_t sstride, u8 *dst, size_t d
     for (int i = 0; i < taps.k; i++) a.taps[i] = taps.t[i];
     a.nstrips = (a.wb + GM_WX - 1) / GM_WX;
     a.nblocks = (h + 15) / 16;
-    // every segment runs two extra blocks (the one above, the one below): long segments, but ~8000 waves (two rounds of the
-    // 16 waves per CU the kernel's LDS allows; measured at 7680x4320x3: 12 segments 0.101 ms, 18 0.083, 23 0.077, 34 0.079)
-    int nsegs = std::max(1, std::min((8192 + a.nstrips - 1) / a.nstrips, (a.nblocks + 3) / 4));
+    // every segment runs two extra blocks (the one above, the one below), yet short segments win: the kernel is bound by
+    // the latency of a block's dependent LDS / MFMA steps at the 4 waves per SIMD its LDS allows, and a finer grain evens
+    // out the rounds (measured at 7680x4320x3: 12 segments per strip 0.099 ms, 18 0.084, 23 0.080, 34 0.074, 46 0.073)
+    int nsegs = std::max(1, std::min((12288 + a.nstrips - 1) / a.nstrips, (a.nblocks + 3) / 4));
     if (const char *e = getenv("IMGPROC_GAUSS_SEGS")) nsegs = std::max(1, std::min(atoi(e), a.nblocks));
     a.seg_blocks = (a.nblocks + nsegs - 1) / nsegs;
     a.nsegs = (a.nblocks + a.seg_blocks - 1) / a.seg_blocks;
