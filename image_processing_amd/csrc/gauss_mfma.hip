@@ -59,11 +59,16 @@ __device__ __forceinline__ long gm_pack(uint32_t lo, uint32_t hi) { return (long
 
 __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
 {
-    // per wave: mid ring [block slot 0..2][byte plane lo/hi][row group of 4][tile][column] and the output staging tile
-    __shared__ uint32_t s_mid[4][3][2][4][GM_NT][16];
+    // per wave: mid ring [block slot 0..2][byte plane lo/hi][tile][row group of 4, Gray-coded][column] and the output
+    // staging tile.  Layouts are chosen against LDS bank conflicts (they were 53 % of the LDS cycles, and the LDS is what
+    // bounds this kernel): a wave's mid write covers 64 consecutive dwords; the column pass reads row groups (2, 3) in
+    // lanes c = 0, 2 and (0, 1) in lanes c = 1, 3 -- Gray-coded group slots 0, 1, 3, 2 put the two on different bank halves;
+    // the stage tile's rows are 15 chunks apart (30 dwords: 16 rows on 16 distinct even banks); the output tile's 4-dword
+    // column groups are XORed with (row >> 1) & 3 (writes 2-way instead of 8-way, the 16-byte reads stay aligned).
+    __shared__ uint32_t s_mid[4][3][2][GM_NT][4][16];
     __shared__ __align__(16) uint32_t s_out[4][16][16];
     __shared__ int s_taps[16];
-    __shared__ __align__(8) uint2 s_stage[4][16][14];  // per wave: one input block between load order and operand order
+    __shared__ __align__(8) uint2 s_stage[4][16][15];  // per wave: one input block between load order and operand order
     __shared__ int s_off[4][8 * 14];  // edge strips: reflected byte offset of every input byte of the strip
     if (threadIdx.x < 16) s_taps[threadIdx.x] = threadIdx.x < 15 ? a.taps[threadIdx.x] : 0;
     __syncthreads();  // the only workgroup barrier, before any wave leaves
@@ -123,8 +128,9 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
     // its branches and runs as a second copy of the loop (EDGE), chosen per wave.
     const int ll = min(lane, 55);
     const int lrow = ll / 14, lq = ll - 14 * lrow;
-    uint2(*stage)[14] = s_stage[wv];  // [16 rows][14 chunks]
-    uint32_t(*mid)[2][4][GM_NT][16] = s_mid[wv];
+    uint2(*stage)[15] = s_stage[wv];  // [16 rows][14 chunks + 1 pad]
+    uint32_t(*mid)[2][GM_NT][4][16] = s_mid[wv];
+    auto gray = [](int g) { return g ^ (g >> 1); };  // row group -> slot inside a tile: 0, 1, 3, 2
     uint32_t(*ost)[16] = s_out[wv];
     const int Bs = seg * a.seg_blocks, Be = min(Bs + a.seg_blocks, a.nblocks);
     auto run = [&](auto edge_c) {
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
             // acc[t][r] = mid[row 4 c + r][column 16 t + i16], 16 bits: low bytes of the four rows -> one dword, high bytes another
             const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)acc[t][1], (uint32_t)acc[t][0], 0x05010400u);
             const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)acc[t][3], (uint32_t)acc[t][2], 0x05010400u);
-            mid[slot][0][c][t][i16] = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
-            mid[slot][1][c][t][i16] = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
+            mid[slot][0][t][gray(c)][i16] = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
+            mid[slot][1][t][gray(c)][i16] = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
         }
         __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order; keep the compiler from reordering
         if (blk < Bs + 1) return;         // the column pass of block ob needs blocks ob - 1, ob, ob + 1
@@ -204,8 +210,8 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
         v4i dlo[GM_NT], dhi[GM_NT];
 #pragma unroll
         for (int t = 0; t < GM_NT; t++) {
-            const long alo = gm_pack(mid[rslot][0][rg][t][i16], mid[rslot][0][rg + 1][t][i16]);
-            const long ahi = gm_pack(mid[rslot][1][rg][t][i16], mid[rslot][1][rg + 1][t][i16]);
+            const long alo = gm_pack(mid[rslot][0][t][gray(rg)][i16], mid[rslot][0][t][gray(rg + 1)][i16]);
+            const long ahi = gm_pack(mid[rslot][1][t][gray(rg)][i16], mid[rslot][1][t][gray(rg + 1)][i16]);
             // sum(tap * mid) = S_lo + 256 S_hi + 128 * 256 * (1 + 256); + 2^15 for the rounding
             const v4i k0 = {8454144, 8454144, 8454144, 8454144}, z = {0, 0, 0, 0};
             dlo[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, colBl, k0, 0, 0, 0);
@@ -217,13 +223,13 @@ __global__ __launch_bounds__(256) void k_gaussian_mfma(const GmArgs a)
 #pragma unroll
             for (int r = 0; r < 4; r++) s[r] = (uint32_t)dlo[t][r] + ((uint32_t)dhi[t][r] << 8);
             // lane (row i16, c): s[r] is column 16 t + 4 c + r; byte 2 of every sum is the result
-            ost[i16][4 * t + c] = __builtin_amdgcn_perm(s[1], s[0], 0x0c0c0602u) | __builtin_amdgcn_perm(s[3], s[2], 0x06020c0cu);
+            ost[i16][4 * (t ^ ((i16 >> 1) & 3)) + c] = __builtin_amdgcn_perm(s[1], s[0], 0x0c0c0602u) | __builtin_amdgcn_perm(s[3], s[2], 0x06020c0cu);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- store: lane l writes bytes [16 (l & 3), +16) of row l >> 2: 64 contiguous bytes per row ----
         {
             const int orow = 16 * ob + (lane >> 2), ox = X + 16 * (lane & 3);
-            const uint4 v = *reinterpret_cast<const uint4 *>(&ost[lane >> 2][4 * (lane & 3)]);
+            const uint4 v = *reinterpret_cast<const uint4 *>(&ost[lane >> 2][4 * ((lane & 3) ^ ((lane >> 3) & 3))]);
             if (orow < h && ox < wb) {
                 u8 *o = a.dst + ((uint32_t)orow * (uint32_t)a.dstride + (uint32_t)ox);
                 if (a.dst_vec && ox + 16 <= wb) {
