@@ -210,7 +210,18 @@ def run_rank(args) -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections ("[Gloo] Rank 0 is connected to ...") on stdout, which has to carry exactly one
+        # JSON line: while the group forms, file descriptor 1 points at stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import image_processing_amd as ip
     from image_processing_amd import _lib as L

@@ -22,8 +22,8 @@ def run_bench(*argv, env_extra=None, timeout=180):
 def test_gpus_2_spawns_two_ranks(config, scaling, frames):
     p = run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--config", config)
     assert p.returncode == 0, p.stderr
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout  # ONE JSON line and nothing else (gloo's chatter goes to stderr)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
     assert out["scaling"] == scaling and out["config"]["dry_run"] is True
