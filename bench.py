@@ -5,7 +5,7 @@ frames/s of the full fused chain (5x5 Gaussian on HSV, HSV inRange, 3x3 erode + 
 GB/s of the chain kernel against the MI355X roofline and the CPU port of the same chain timed on the
 host's cores.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5|pp|pe]
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5|pp|pe]
 
 --gpus N > 1 without WORLD_SIZE in the environment: this process (which never touches the GPU) starts N
 rank processes itself, one per GPU, and relays rank 0's JSON line.  Under torch.distributed.run
@@ -17,6 +17,8 @@ cross-frame step).  The only inter-rank traffic is the timing barrier / max-redu
 gather of the per-frame moments (control plane, gloo).
 
 Configurations (BASELINE.json `configs`):
+  c1  configs[0]  640x480 BGR8, HSV inRange + 3x3 erode + 3x3 dilate + centroid, no blur: the reference's own CPU-runnable
+                  case.  The CPU leg (`cpu_baseline`) is this configuration's subject; the GPU leg is timed beside it
   c2  configs[1]  1920x1200 BGR8, 256 frames per GPU per step, G5 -> inRange -> E3 -> D3 -> moments        (weak scaling)
   c3  configs[2]  2448x2048 BayerRG8, demosaic inside the chain kernel, 64 frames per GPU per step; plus the
                   streamed leg (host frames -> pinned slots -> H2D -> chain), reported beside it, never as `value`
@@ -40,8 +42,13 @@ sys.path.insert(0, ROOT)
 
 PREROLL_S = 0.15  # untimed steady-state pre-roll before the warmup steps (GPU clock ramp)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# wave64 VALU: 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz, one op per lane and cycle
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
+# wave64 VALU, the machine's peak: 256 CUs x 4 SIMD-32 x 32 lanes per cycle at 2.4 GHz (MI355X_MICROARCH.md: a wave64
+# instruction issues over 2 cycles; = the 157.3 TFLOP/s fp32 FMA spec / 2).  Only the cheap instruction class (add / sub /
+# and / or / xor / not / lshr / ashr / mov / cndmask / bitop3 / f32 add-mul-fma) reaches it, and only in a stream of its own
+# kind; everything else (shifts left, 3-input integer ops, min / max, mad24, compares, perm, alignbit, bcnt, every packed,
+# DPP and SDWA form) takes 4 cycles (profiles/r03_issue_rate_ubench.log).
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+N_SIMDS = 256 * 4
 STREAM_FRAMES_C4 = 4096
 
 
@@ -52,6 +59,12 @@ def config_table():
 
     bands = [(20 * i, 20 * i + 19) for i in range(8)]
     return {
+        "c1": dict(w=640, h=480, enc=L.ENC_BGR8, batch=64, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+                   pipe=dict(morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE], cpu_budget_s=20.0,
+                   metric="frames/sec at 640x480 BGR8, HSV inRange + 3x3 erode + 3x3 dilate + centroid (no blur)",
+                   workload="configs[0] (the reference's CPU-runnable case, pose_estimate.cpp:203-206,405-415 with one erode and one "
+                            "dilate): 640x480 BGR8, batches of 64 frames, BGR2HSV + inRange + erode3 + dilate3 + moments; the CPU leg "
+                            "(`cpu_baseline`) is this configuration's subject, `value` is the GPU leg (device-resident) beside it"),
         "c2": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
                    pipe=dict(post_blur_k=5, morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE],
                    metric="frames/sec at 1920x1200 BGR8, full chain (5x5 Gaussian, HSV inRange, 3x3 erode+dilate, moments)",
@@ -150,7 +163,7 @@ def cpu_baseline(cfg: dict, frames, threads: int, budget_s: float = 12.0) -> dic
     t0 = time.perf_counter()
     one(0)
     t1 = time.perf_counter() - t0  # one frame on one thread
-    per_thread = max(1, min(8, int(budget_s / max(t1, 1e-3))))
+    per_thread = max(1, min(8 if budget_s <= 12.0 else 4096, int(budget_s / max(t1, 1e-3))))
     n_frames = per_thread * threads
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside the C call
@@ -181,15 +194,53 @@ def kernel_name(cfg: dict, plan: str) -> str:
     return f"all chain kernels of one batch ({plan})"
 
 
+def build_hashes() -> dict:
+    """Identity of the kernel build this process runs: sha256[:16] of the loaded libimgproc_hip.so and of the sources it is
+    built from (csrc/* + include/imgproc.h, names and contents).  scripts/pmc_collect.py records the same two."""
+    import hashlib
+
+    from image_processing_amd import _lib as L
+
+    out = {"lib_sha16": None, "src_sha16": None}
+    if os.path.exists(L.LIB_PATH):
+        with open(L.LIB_PATH, "rb") as f:
+            out["lib_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "image_processing_amd", "csrc")
+    files = sorted(os.path.join(csrc, n) for n in os.listdir(csrc)) + [os.path.join(ROOT, "include", "imgproc.h")]
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    out["src_sha16"] = h.hexdigest()[:16]
+    return out
+
+
 def offline_counters(name: str):
     """PMC figures of this configuration's chain kernel(s) from the committed rocprofv3 --pmc passes (profiles/): HBM
-    bytes and VALU instructions per launch.  They are properties of the kernel build and the workload shape, not of
-    this run: labelled as such in the JSON, None when the file is absent or does not cover the configuration."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    if not os.path.exists(path):
-        return None, None
+    bytes, VALU instructions and the clock per launch.  They are properties of the kernel build and the workload shape,
+    not of this run, so they are quoted only when they were collected on THIS build: the summary's lib_sha16 must equal
+    the loaded library's hash (or its src_sha16 the hash of the sources the library is built from); otherwise
+    (None, reason)."""
+    for name_ in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name_)
+        if os.path.exists(path):
+            break
+    else:
+        return None, "no profiles/r0x_pmc_summary.json"
     with open(path) as f:
-        return json.load(f).get(name), os.path.relpath(path, ROOT)
+        pmc = json.load(f).get(name)
+    rel = os.path.relpath(path, ROOT)
+    if not pmc:
+        return None, f"{rel} does not cover this configuration"
+    mine = build_hashes()
+    same_lib = pmc.get("lib_sha16") and pmc.get("lib_sha16") == mine["lib_sha16"]
+    same_src = pmc.get("src_sha16") and pmc.get("src_sha16") == mine["src_sha16"]
+    if not (same_lib or same_src):
+        return None, (f"{rel} was collected on another kernel build (lib {pmc.get('lib_sha16')}, src {pmc.get('src_sha16')}; loaded: "
+                      f"lib {mine['lib_sha16']}, src {mine['src_sha16']}): not quoted")
+    pmc = dict(pmc, matched_on="lib_sha16" if same_lib else "src_sha16")
+    return pmc, rel
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -361,7 +412,10 @@ def run_rank(args) -> None:
     gather_ms = (time.perf_counter() - t_g) * 1e3
     n_found = int((centroids(gathered)[:, 0, 0] >= 0).sum()) if rank == 0 else 0
 
+    checked = False
     if args.check and rank == 0:
+        # one frame of the last batch against the oracle, after the timed region (every run, unless --no-check): the
+        # number above is worth nothing if the masks and moments it produced are wrong
         from oracle import Oracle
 
         i = min(9, batches[-1][1] - 1)
@@ -375,6 +429,7 @@ def run_rank(args) -> None:
             assert (got[r] == exp["mask"][r]).all(), f"bench mask of range {r} != oracle"
             idx = batches[-1][2] - a + i
             assert [int(v) for v in local[idx, r]] == [int(v) for v in exp["moments"][r][:3]], "bench moments != oracle"
+        checked = True
 
     if rank == 0:
         fps = frames_per_step_total * args.steps / dt
@@ -390,25 +445,47 @@ def run_rank(args) -> None:
                 "kernel_ms_per_batch": k_ms, "launches_per_batch": launches,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_px": cfg["bpp"]}
         pmc, src = offline_counters(args.config if not args.unfused else "none")
-        if pmc and abs(pmc.get("frames_per_launch", 0) - bytes_per_launch / algo_bytes) < 0.5:
+        if pmc is None:
+            roof["traffic_source"] = src  # why nothing is quoted
+        elif abs(pmc.get("frames_per_launch", 0) - bytes_per_launch / algo_bytes) >= 0.5:
+            roof["traffic_source"] = f"{src} covers {pmc.get('frames_per_launch')} frames per launch, this run {bytes_per_launch / algo_bytes:.0f}: not quoted"
+        else:
             # HBM bytes from rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE, separate runs, the
-            # guide's gfx950 corrections); VALU instructions likewise -- offline figures of the kernel, not of this run
+            # guide's gfx950 corrections); VALU instructions and the clock (GRBM_GUI_ACTIVE) likewise -- offline figures
+            # of this kernel build (hash-checked), not of this run
             roof["traffic"] = pmc.get("hbm_bytes_per_launch")
-            roof["traffic_source"] = f"{src} (offline rocprofv3 --pmc passes of this command, kernel build {pmc.get('lib_sha16')})"
+            roof["traffic_source"] = (f"{src} (offline rocprofv3 --pmc passes of this command on this kernel build, matched on "
+                                      f"{pmc['matched_on']} {pmc.get(pmc['matched_on'])})")
             if pmc.get("valu_insts_per_launch"):
-                lane_ops = pmc["valu_insts_per_launch"] * 64 / (k_ms * 1e-3)
-                roof["valu"] = {"achieved_lane_ops_per_s": lane_ops, "peak": VALU_PEAK_LANE_OPS, "frac": lane_ops / VALU_PEAK_LANE_OPS,
-                                "valu_insts_per_launch": pmc["valu_insts_per_launch"],
-                                "lane_ops_per_px": pmc["valu_insts_per_launch"] * 64 / (bytes_per_launch / cfg["bpp"]),
-                                "insts_source": roof["traffic_source"],
-                                "note": "the kernel is VALU-issue-bound: this fraction, not the HBM one, is what is saturated"}
+                n_valu = pmc["valu_insts_per_launch"]
+                lane_ops = n_valu * 64 / (k_ms * 1e-3)
+                clock = pmc.get("clock_ghz") or 2.4
+                valu = {"achieved_lane_ops_per_s": lane_ops, "peak": VALU_PEAK_LANE_OPS, "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                        "peak_note": "machine peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (one wave64 instruction per 2 cycles); "
+                                     "reached only by a stream of cheap-class instructions",
+                        "valu_insts_per_launch": n_valu,
+                        "lane_ops_per_px": n_valu * 64 / (bytes_per_launch / cfg["bpp"]),
+                        "clock_ghz": clock, "clock_source": "GRBM_GUI_ACTIVE / 8 / kernel time (offline pass)" if pmc.get("clock_ghz") else "assumed",
+                        "cycles_per_valu_inst": k_ms * 1e-3 * clock * 1e9 * N_SIMDS / n_valu,
+                        "insts_source": roof["traffic_source"]}
+                cheap = pmc.get("cheap_class_share")  # static share of cheap-class instructions in the main loop (ISA count)
+                if cheap is not None:
+                    # issue-class floor: every cheap-class instruction at 2 cycles, every other at 4, nothing else in the way
+                    floor_ms = n_valu * (2.0 * cheap + 4.0 * (1.0 - cheap)) / N_SIMDS / (clock * 1e9) * 1e3
+                    valu["issue_class"] = {"cheap_class_share": cheap, "floor_ms_cheap2_full4": floor_ms, "frac_of_floor": floor_ms / k_ms,
+                                           "note": "floor = every cheap-class instruction at 2 cycles, every other at 4 (frac_of_floor = floor / "
+                                                   "measured kernel time).  Mixed streams do not reach it: with 25-75 % of full-rate-class "
+                                                   "instructions, in runs of 1 to 48, the micro-benchmark pays 3.6-4.1 cycles for EVERY "
+                                                   "instruction (profiles/r03_issue_rate_ubench.log); cycles_per_valu_inst above is this "
+                                                   "kernel's figure"}
+                roof["valu"] = valu
         out = {
             "metric": cfg["metric"], "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": cfg["workload"] + "; two batches in flight (results of batch k are collected after batch k+1 "
                                                     "is enqueued)",
-                       "name": args.config, "frames_per_step": frames_per_step_total, "frames_per_batch": pool_n, "width": W,
+                       "name": args.config, "checked": checked, "frames_per_step": frames_per_step_total, "frames_per_batch": pool_n, "width": W,
                        "height": H, "n_ranges": nr, "untimed_preroll_s": PREROLL_S,
                        "path": plan if not args.unfused else f"stage-by-stage ({launches} launches per batch)",
                        "sharding": f"frames x{world} ranks ({cfg['scaling']}), no collective; {frames_per_step_total} centroids "
@@ -420,7 +497,7 @@ def run_rank(args) -> None:
             out["streamed"] = streamed_leg(cfg, base_np, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(cfg, base_np, threads)
+            out["cpu_baseline"] = cpu_baseline(cfg, base_np, threads, budget_s=cfg.get("cpu_budget_s", 12.0))
         print(json.dumps(out), flush=True)
     g.close()
     if dist is not None:
@@ -489,13 +566,16 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "pp", "pe"], default="c2")
+    ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5", "pp", "pe"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true", help="c3: skip the streamed (PCIe) leg")
     ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")
-    ap.add_argument("--check", action="store_true", help="also verify one frame of the last batch against the oracle")
+    ap.add_argument("--no-check", dest="check", action="store_false",
+                    help="skip the oracle check of one frame of the last batch (it runs after the timed region by default)")
+    ap.add_argument("--check", dest="check", action="store_true", help="(default) verify one frame of the last batch against the oracle")
+    ap.set_defaults(check=True)
     args = ap.parse_args()
-    defaults = {"c2": (100, 20), "c3": (50, 10), "c4": (5, 1), "c5": (20, 4), "pp": (60, 10), "pe": (60, 10)}[args.config]
+    defaults = {"c1": (200, 40), "c2": (100, 20), "c3": (50, 10), "c4": (5, 1), "c5": (20, 4), "pp": (60, 10), "pe": (60, 10)}[args.config]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
@@ -508,7 +588,7 @@ def main() -> int:
         argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config]
         argv += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
         argv += ["--unfused"] if args.unfused else []
-        argv += ["--check"] if args.check else []
+        argv += [] if args.check else ["--no-check"]
         return spawn_ranks(args.gpus, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:

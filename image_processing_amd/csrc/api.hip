@@ -38,6 +38,9 @@ static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
 constexpr int NA_MAX_DEVICES = 64;
 static unsigned char *g_scratch_ptr[NA_MAX_DEVICES];
 static std::mutex g_scratch_mu;
+// one no-allocation call at a time per GPU: the call is synchronous, so the flag is held from its first use of the array to
+// after its stream synchronize; a second context / thread on the same GPU gets IMGPROC_ESTATE instead of corrupted sums
+static std::atomic<bool> g_scratch_busy[NA_MAX_DEVICES];
 
 namespace {
 
@@ -203,7 +206,8 @@ struct imgproc_ctx {
     int *d_tables = nullptr;
     ipm::Group *d_groups = nullptr;  // device copy of plan.bm.groups (32 entries)
     std::vector<Slot> slots;
-    Slot work;  // scratch planes of the device-batch and single-stage paths (never visible to submit / wait / fetch_stage)
+    Slot work;  // scratch planes of the stage-by-stage device-batch path and imgproc_mask_and (ensure_work: on first use)
+    bool work_ready = false;
     Plan plan;
     struct Batch {  // one of the two in-flight device batches (imgproc_batch_enqueue / imgproc_batch_wait)
         unsigned long long *d_mom = nullptr, *h_mom = nullptr;
@@ -369,13 +373,16 @@ int alloc_slot(imgproc_ctx *c, Slot &s, bool staging = true)
     if (staging) HIPCHK(c, hipHostMalloc((void **)&s.h_in, px * 3, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&s.h_mom, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES, hipHostMallocDefault));
     memset(s.h_mom, 0, sizeof(unsigned long long) * 6 * IMGPROC_MAX_RANGES);
-    HIPCHK(c, hipMalloc((void **)&s.d_raw, px * 3));
+    if (staging) HIPCHK(c, hipMalloc((void **)&s.d_raw, px * 3));  // the work slot reads the caller's device frames in place
     HIPCHK(c, hipMalloc((void **)&s.d_a, px * 3));
     HIPCHK(c, hipMalloc((void **)&s.d_b, px * 3));
     HIPCHK(c, hipMalloc((void **)&s.d_bgr, px * 3));
     HIPCHK(c, hipMalloc((void **)&s.d_t, px * 3));
-    HIPCHK(c, hipMalloc((void **)&s.d_masked, px * 3));
-    HIPCHK(c, hipMalloc((void **)&s.d_thresh, px * IMGPROC_MAX_RANGES));
+    if (staging) HIPCHK(c, hipMalloc((void **)&s.d_masked, px * 3));
+    // inRange planes: bytes (px per range) or bit planes (h rows of ceil(w / 32) words per range) -- for frames narrower
+    // than 4 px the bit planes are the larger of the two
+    const size_t bit_plane = (size_t)c->cfg.max_height * 4 * (((size_t)c->cfg.max_width + 31) / 32);
+    HIPCHK(c, hipMalloc((void **)&s.d_thresh, std::max(px, bit_plane) * IMGPROC_MAX_RANGES));
     HIPCHK(c, hipMalloc((void **)&s.d_mask, px * IMGPROC_MAX_RANGES));
     HIPCHK(c, hipMalloc((void **)&s.d_m0, px));
     HIPCHK(c, hipMalloc((void **)&s.d_m1, px));
@@ -471,6 +478,20 @@ int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, i
         }
     }
     if (launches) *launches += nl;
+    return 0;
+}
+
+// The context's work slot (planes of the stage-by-stage device-batch path and of imgproc_mask_and) is allocated on its
+// first use: ~30 B/px that callers of the streaming path, the chain kernel or the front + bit-plane path never pay.
+int ensure_work(imgproc_ctx *c)
+{
+    if (c->work_ready) return 0;
+    int rc = alloc_slot(c, c->work, false);
+    if (rc) {
+        free_slot(c->work);
+        return rc;
+    }
+    c->work_ready = true;
     return 0;
 }
 
@@ -591,7 +612,7 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
             int rc = alloc_slot(c, s);
             if (rc) return rc;
         }
-        return alloc_slot(c, c->work, false);
+        return 0;
     };
     int rc;
     try {
@@ -1022,6 +1043,8 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
                                        p.pipe.second_order, c->stream, bits));
         bt.launches = 2;
     } else if (bit_plane_tail(p)) {
+        rc = ensure_work(c);
+        if (rc) return rc;
         // stage kernels per frame up to the inRange bit planes, then the bit-plane morphology of a whole group of frames in
         // one launch (planes = frames x ranges): at one 8K frame it has too few independent columns to fill the chip
         const size_t per_frame = (size_t)nr * h * ipm::bit_words(w) * 4;
@@ -1050,6 +1073,8 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
             bt.launches++;
         }
     } else {
+        rc = ensure_work(c);
+        if (rc) return rc;
         for (int i = 0; i < n; i++) {
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;
             rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)i * frame_stride, row_stride, w, h, mout,
@@ -1120,6 +1145,10 @@ IMGPROC_API int imgproc_process_batch_device_noalloc(imgproc_ctx *c, const void 
     unsigned long long *d_mom = reinterpret_cast<unsigned long long *>(c->na_scratch);
     u8 *d_planes = c->na_scratch + NA_MOM_BYTES;
     const size_t mom_bytes = sizeof(unsigned long long) * 6 * nr * (size_t)n;
+    struct Busy {  // released on every return path below
+        std::atomic<bool> *f = nullptr;
+        ~Busy() { if (f) f->store(false, std::memory_order_release); }
+    } busy;
     const bool chain = p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks);
     const bool front = !chain && p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks);
     if (!chain && !front)
@@ -1129,6 +1158,10 @@ IMGPROC_API int imgproc_process_batch_device_noalloc(imgproc_ctx *c, const void 
     if (front && (size_t)n * nr * plane_bytes > NA_PLANE_BYTES)
         return fail(c, IMGPROC_ESIZE, "no-allocation path: %d frames x %d ranges x %dx%d inRange planes (%zu bytes each) > %zu scratch bytes",
                     n, nr, w, h, plane_bytes, NA_PLANE_BYTES);
+    if (g_scratch_busy[c->cfg.device].exchange(true, std::memory_order_acquire))
+        return fail(c, IMGPROC_ESTATE, "no-allocation path: another call is using GPU %d's scratch array (one such call per GPU at a time)",
+                    c->cfg.device);
+    busy.f = &g_scratch_busy[c->cfg.device];
     // the array keeps the last call's contents: the sums must start at zero (the planes are fully rewritten)
     HIPCHK(c, hipMemsetAsync(d_mom, 0, mom_bytes, c->stream));
     if (chain) {
@@ -1276,6 +1309,8 @@ IMGPROC_API int imgproc_mask_and(imgproc_ctx *c, const uint8_t *bgr, size_t sstr
     if (rc) return rc;
     if (mstride < (size_t)w) return fail(c, IMGPROC_EINVAL, "mask stride too small");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    rc = ensure_work(c);
+    if (rc) return rc;
     Slot &s = c->work;
     UPLOAD(c, c->d_s0, bgr, sstride, rowb, h);
     UPLOAD(c, s.d_m0, mask, mstride, (size_t)w, h);

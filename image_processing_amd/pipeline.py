@@ -62,6 +62,10 @@ class ImgProc:
     # -- lifecycle ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
+            # page-locked arrays still out (host_alloc without host_free) go with the context: after close() they dangle
+            for p, _ in list(getattr(self, "_pinned", {}).values()):
+                self.lib.imgproc_host_free(self._ctx, p)
+            self._pinned = {}
             self.lib.imgproc_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -141,20 +145,37 @@ class ImgProc:
         self._slot_dims[slot] = (h, w)
 
     def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
-        """A numpy array over page-locked host memory; release with host_free(arr)."""
+        """A numpy array over page-locked host memory; release with host_free(arr).  The array does NOT own the memory:
+        after host_free(arr) (or close()) the array and every view / slice of it point at freed pages, and touching
+        one is a use-after-free (a segmentation fault, as gpurun_out/pinned.log of round 2 shows).  Copy what is
+        needed (`arr[i].copy()`) and drop the views before host_free; host_free refuses while it can see other
+        references to the array."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = C.c_void_p()
         self._chk(self.lib.imgproc_host_alloc(self._ctx, max(n, 1), C.byref(p)), "imgproc_host_alloc")
         buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        import weakref
+
         self._pinned = getattr(self, "_pinned", {})
-        self._pinned[arr.ctypes.data] = p.value
+        self._pinned[arr.ctypes.data] = (p.value, weakref.ref(arr))  # the array itself, not a view that starts at its address
         return arr
 
-    def host_free(self, arr: np.ndarray):
-        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
-        if p is not None:
-            self._chk(self.lib.imgproc_host_free(self._ctx, p), "imgproc_host_free")
+    def host_free(self, arr: np.ndarray, force: bool = False):
+        """Releases a host_alloc array.  Views of it (`arr[i]`, reshapes) keep a reference to `arr`; while any is alive
+        besides the caller's own name for the array the call raises ImgProcError(ESTATE) instead of leaving them
+        dangling (force=True frees anyway)."""
+        import sys
+
+        pinned = getattr(self, "_pinned", {})
+        if arr.ctypes.data not in pinned or pinned[arr.ctypes.data][1]() is not arr:
+            raise ImgProcError(L.EINVAL, "host_free", "not an array handed out by host_alloc (a view of one?)")
+        # 3 = the caller's name, this parameter, getrefcount's own argument
+        if not force and sys.getrefcount(arr) > 3:
+            raise ImgProcError(L.ESTATE, "host_free", f"{sys.getrefcount(arr) - 3} other reference(s) to the array are alive "
+                               "(views, slices, containers): drop them first, or pass force=True")
+        p = pinned.pop(arr.ctypes.data)[0]
+        self._chk(self.lib.imgproc_host_free(self._ctx, p), "imgproc_host_free")
 
     def wait(self, slot: int):
         r = L.Result()

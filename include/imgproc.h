@@ -165,16 +165,18 @@ int imgproc_batch_enqueue(imgproc_ctx *ctx, const void *d_frames, size_t frame_s
                           int n, void *d_masks, int ticket);
 int imgproc_batch_wait(imgproc_ctx *ctx, int ticket, imgproc_result *out);
 
-/* imgproc_process_batch_device for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results
- * as imgproc_process_batch_device, but the library's scratch (the moment sums; the inRange planes between the
- * front kernel and the bit-plane kernel) lives in a static per-GPU device array of 32 MiB + 384 KiB instead of
- * allocated buffers, and the call makes no hipMalloc / hipFree / hipHostMalloc.  Limits: n <= max_batch,
- * n * n_ranges <= 8192, and for pipelines that run as front kernel + bit-plane morphology the inRange planes
- * (n * n_ranges * h * 4 * ceil(w / 32) bytes as bit planes; n * n_ranges * w * h when w % 4 != 0) <= 32 MiB
- * (IMGPROC_ESIZE beyond); pipelines or frame shapes that run stage by stage
- * return IMGPROC_EUNSUPPORTED.  Synchronous (returns with `out` filled).  Every call on a GPU shares that GPU's
- * array: calls that overlap on one GPU (two contexts, two threads) race. */
+/* imgproc_process_batch_device for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc after start-up, processes that share a GPU whose memory is fully committed).  It has no counterpart in
+ * the reference.  Same arguments and results as imgproc_process_batch_device, but the library's scratch (the
+ * moment sums; the inRange planes between the front kernel and the bit-plane kernel) lives in a static per-GPU
+ * device array of 32 MiB + 384 KiB instead of allocated buffers, and the call makes no hipMalloc / hipFree /
+ * hipHostMalloc.  Limits: n <= max_batch, n * n_ranges <= 8192, and for pipelines that run as front kernel +
+ * bit-plane morphology the inRange planes (n * n_ranges * h * 4 * ceil(w / 32) bytes as bit planes;
+ * n * n_ranges * w * h when w % 4 != 0) <= 32 MiB (IMGPROC_ESIZE beyond); pipelines or frame shapes that run stage
+ * by stage return IMGPROC_EUNSUPPORTED.  Synchronous on the context's own stream: it enqueues there, waits for the
+ * stream and returns with `out` filled, so it cannot be part of a caller's HIP graph capture (it does not take the
+ * caller's stream, and the wait is illegal under capture).  Every call on a GPU shares that GPU's array: while one call
+ * is inside it, a second one on the same GPU (another context, another thread) returns IMGPROC_ESTATE. */
 int imgproc_process_batch_device_noalloc(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride,
                                          size_t row_stride, int w, int h, int n, void *d_masks, imgproc_result *out);
 

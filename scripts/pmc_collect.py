@@ -27,7 +27,7 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recurs
     for r in csv.DictReader(open(f)):
         if ours(r["Name"]):
             kern[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])}
-for pas in ("fetch", "write", "sq1", "sq2"):
+for pas in ("fetch", "write", "grbm", "sq1", "sq2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(out, pas, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -44,4 +44,8 @@ for ln in open(os.path.join(out, "stats.log")):
         bench = json.loads(ln)
 lib = os.path.join(ROOT, "image_processing_amd", "lib", "libimgproc_hip.so")
 sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
-print(json.dumps({"config": cfg, "lib_sha16": sha, "bench_line_under_rocprof": bench, "kernels": kern}, indent=1))
+sys.path.insert(0, ROOT)
+from bench import build_hashes  # the same two hashes bench.py compares at run time
+
+assert build_hashes()["lib_sha16"] == sha
+print(json.dumps({"config": cfg, "lib_sha16": sha, "src_sha16": build_hashes()["src_sha16"], "bench_line_under_rocprof": bench, "kernels": kern}, indent=1))

@@ -65,6 +65,79 @@
 #define T_cvt_ub(i) "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
 #define T_fma(i) "v_fma_f32 %" #i ", %" #i ", %16, %17\n"
 #define T_add_u16(i) "v_add_u16 %" #i ", %" #i ", %16\n"
+// ---- round 3: the lane-mask readers (v_cndmask 22.7 cycles?) and more opcodes ----
+#define T_or(i) "v_or_b32 %" #i ", %" #i ", %16\n"
+#define T_ashr(i) "v_ashrrev_i32 %" #i ", 3, %" #i "\n"
+#define T_lshl1(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define T_subrev(i) "v_subrev_u32 %" #i ", %" #i ", %16\n"
+#define T_not(i) "v_not_b32 %" #i ", %" #i "\n"
+#define T_min(i) "v_min_u32 %" #i ", %" #i ", %16\n"
+#define T_and_or(i) "v_and_or_b32 %" #i ", %" #i ", %16, %17\n"
+#define T_or3(i) "v_or3_b32 %" #i ", %" #i ", %16, %17\n"
+#define T_bfi(i) "v_bfi_b32 %" #i ", %" #i ", %16, %17\n"
+#define T_add_lshl(i) "v_add_lshl_u32 %" #i ", %" #i ", %16, 2\n"
+#define T_mul24(i) "v_mul_u32_u24 %" #i ", %" #i ", %16\n"
+#define T_add_co(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %16\n"
+#define T_addc_vcc(i) "v_addc_co_u32 %" #i ", vcc, %" #i ", %" #i ", vcc\n"
+#define T_addc_sgpr(i) "v_addc_co_u32 %" #i ", vcc, %" #i ", %" #i ", s[20:21]\n"
+#define T_cndmask_sgpr(i) "v_cndmask_b32 %" #i ", %" #i ", %16, s[20:21]\n"
+#define T_cmp_sgpr(i) "v_cmp_eq_u32 s[22:23], %" #i ", %16\n"
+#define T_cmp_lt(i) "v_cmp_lt_u32 vcc, %" #i ", %16\n"
+#define T_cndmask_e32(i) "v_cndmask_b32_e32 %" #i ", %" #i ", %16, vcc\n"
+#define T_sub_co(i) "v_sub_co_u32 %" #i ", vcc, %" #i ", %16\n"
+#define T_mov_sgpr(i) "v_mov_b32 %" #i ", s20\n"
+#define T_add_sgpr(i) "v_add_u32 %" #i ", s20, %" #i "\n"
+#define T_max3_sgpr(i) "v_max3_u32 %" #i ", %" #i ", s20, %17\n"
+#define T_pk_sub_sgpr(i) "v_pk_sub_u16 %" #i ", %" #i ", s20\n"
+#define T_fmac(i) "v_fmac_f32 %" #i ", %16, %17\n"
+#define T_mul_f32(i) "v_mul_f32 %" #i ", %" #i ", %16\n"
+#define T_add_f32(i) "v_add_f32 %" #i ", %" #i ", %16\n"
+#define T_xad(i) "v_xad_u32 %" #i ", %" #i ", %16, %17\n"
+#define T_lshl_or(i) "v_lshl_or_b32 %" #i ", %" #i ", 2, %16\n"
+#define T_sub_sdwa_free(i) "v_sub_u32 %" #i ", %16, %" #i "\n"
+// the KERNEL macro with s[20:23] written before the loop (a lane mask in SGPRs, as a v_cmp would leave it)
+#define KERNEL_S(NAME, BODY)                                                                                           \
+    __global__ __launch_bounds__(256) void NAME(uint32_t *out, uint32_t seed)                                          \
+    {                                                                                                                  \
+        uint32_t r[16];                                                                                                \
+        for (int i = 0; i < 16; i++) r[i] = threadIdx.x * 17 + i + seed;                                               \
+        uint32_t x = seed * 3 + threadIdx.x, y = seed ^ 0x5555;                                                        \
+        asm volatile("s_mov_b32 s20, 0x55aa55aa\ns_mov_b32 s21, 0x0f0f3c3c\ns_mov_b64 s[22:23], 0\ns_mov_b64 vcc, s[20:21]" ::: "s20", "s21", "s22", "s23", "vcc"); \
+        for (int it = 0; it < ITER; it++)                                                                              \
+            asm volatile(BODY : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]),    \
+                         "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]),       \
+                         "+v"(r[14]), "+v"(r[15]) : "v"(x), "v"(y) : "vcc", "s20", "s21", "s22", "s23");               \
+        uint32_t a = 0;                                                                                                \
+        for (int i = 0; i < 16; i++) a ^= r[i];                                                                        \
+        out[blockIdx.x * 256 + threadIdx.x] = a;                                                                       \
+    }
+#define RUN2(A, B) A(0) A(1) B(2) B(3) A(4) A(5) B(6) B(7) A(8) A(9) B(10) B(11) A(12) A(13) B(14) B(15)
+#define RUN4(A, B) A(0) A(1) A(2) A(3) B(4) B(5) B(6) B(7) A(8) A(9) A(10) A(11) B(12) B(13) B(14) B(15)
+#define RUN8(A, B) A(0) A(1) A(2) A(3) A(4) A(5) A(6) A(7) B(8) B(9) B(10) B(11) B(12) B(13) B(14) B(15)
+#define MIX3_1(A, B) A(0) A(1) A(2) B(3) A(4) A(5) A(6) B(7) A(8) A(9) A(10) B(11) A(12) A(13) A(14) B(15)
+#define MIX2_2x(A, B) A(0) A(1) B(2) A(3) A(4) B(5) A(6) A(7) B(8) A(9) A(10) B(11) A(12) A(13) B(14) B(15)
+KERNEL_S(k2_or, R16(T_or)) KERNEL_S(k2_ashr, R16(T_ashr)) KERNEL_S(k2_lshl1, R16(T_lshl1)) KERNEL_S(k2_subrev, R16(T_subrev))
+KERNEL_S(k2_not, R16(T_not)) KERNEL_S(k2_min, R16(T_min)) KERNEL_S(k2_and_or, R16(T_and_or)) KERNEL_S(k2_or3, R16(T_or3))
+KERNEL_S(k2_bfi, R16(T_bfi)) KERNEL_S(k2_add_lshl, R16(T_add_lshl)) KERNEL_S(k2_mul24, R16(T_mul24)) KERNEL_S(k2_add_co, R16(T_add_co))
+KERNEL_S(k2_addc_vcc, R16(T_addc_vcc)) KERNEL_S(k2_addc_sgpr, R16(T_addc_sgpr)) KERNEL_S(k2_cndmask_vcc, R16(T_cndmask))
+KERNEL_S(k2_cndmask_sgpr, R16(T_cndmask_sgpr)) KERNEL_S(k2_cmp_sgpr, R16(T_cmp_sgpr)) KERNEL_S(k2_cndmask_e32, R16(T_cndmask_e32))
+KERNEL_S(k2_alt_cmp_cndmask, ALT(T_cmp_lt, T_cndmask)) KERNEL_S(k2_alt_cmpsgpr_cndmask, ALT(T_cmp_sgpr, T_cndmask_sgpr))
+KERNEL_S(k2_alt_add_cndmask, ALT(T_add, T_cndmask)) KERNEL_S(k2_sub_co, R16(T_sub_co))
+KERNEL_S(k2_mov_sgpr, R16(T_mov_sgpr)) KERNEL_S(k2_add_sgpr, R16(T_add_sgpr)) KERNEL_S(k2_max3_sgpr, R16(T_max3_sgpr))
+KERNEL_S(k2_pk_sub_sgpr, R16(T_pk_sub_sgpr)) KERNEL_S(k2_fmac, R16(T_fmac)) KERNEL_S(k2_mul_f32, R16(T_mul_f32))
+KERNEL_S(k2_add_f32, R16(T_add_f32)) KERNEL_S(k2_xad, R16(T_xad)) KERNEL_S(k2_lshl_or, R16(T_lshl_or))
+// run lengths of a cheap kind (add) among a full-rate kind (max3), 8 + 8 per iteration
+KERNEL_S(k2_run1_add_max3, ALT(T_add, T_max3)) KERNEL_S(k2_run2_add_max3, RUN2(T_add, T_max3)) KERNEL_S(k2_run4_add_max3, RUN4(T_add, T_max3))
+KERNEL_S(k2_run8_add_max3, RUN8(T_add, T_max3)) KERNEL_S(k2_mix2_1_add_max3, MIX2_2x(T_add, T_max3))
+#define RUN12_4(A, B) A(0) A(1) A(2) A(3) A(4) A(5) A(6) A(7) A(8) A(9) A(10) A(11) B(12) B(13) B(14) B(15)
+#define PAT_1_3(A, B) A(0) B(1) B(2) B(3) A(4) B(5) B(6) B(7) A(8) B(9) B(10) B(11) A(12) B(13) B(14) B(15)
+KERNEL_S(k2_run12_4_add_max3, RUN12_4(T_add, T_max3)) KERNEL_S(k2_cmp_cnd3, PAT_1_3(T_cmp_lt, T_cndmask))
+KERNEL_S(k2_run2_add_cnd, RUN2(T_add, T_cndmask)) KERNEL_S(k2_run4_add_cnd, RUN4(T_add, T_cndmask))
+// longer runs: 16 + 16, 48 + 16 (75 % cheap), 16 + 48 (25 % cheap: the chain kernel's share) per iteration
+KERNEL_S(k2_run16_16_add_max3, R16(T_add) R16(T_max3)) KERNEL_S(k2_run48_16_add_max3, R16(T_add) R16(T_add) R16(T_add) R16(T_max3))
+KERNEL_S(k2_run16_48_add_max3, R16(T_add) R16(T_max3) R16(T_max3) R16(T_max3))
+KERNEL_S(k2_run2_add_cmp, RUN2(T_add, T_cmp)) KERNEL_S(k2_run2_and_perm, RUN2(T_and, T_perm)) KERNEL_S(k2_run2_sub_mad24, RUN2(T_sub, T_mad24))
+KERNEL_S(k2_run2_add_dpp, RUN2(T_add, T_dpp_add)) KERNEL_S(k2_run4_add_lshl_add, RUN4(T_add, T_lshl_add))
 KERNEL(k_add, R16(T_add)) KERNEL(k_sub, R16(T_sub)) KERNEL(k_and, R16(T_and)) KERNEL(k_xor, R16(T_xor))
 KERNEL(k_lshr, R16(T_lshr)) KERNEL(k_lshl, R16(T_lshl)) KERNEL(k_mov, R16(T_mov)) KERNEL(k_cndmask, R16(T_cndmask))
 KERNEL(k_bitop3, R16(T_bitop3)) KERNEL(k_add3, R16(T_add3)) KERNEL(k_lshl_add, R16(T_lshl_add)) KERNEL(k_max3, R16(T_max3))
@@ -112,7 +185,15 @@ struct Ent { const char *name; kfn f; double insts_per_iter; };
 #define E(N) {#N, N, 16.0}
 int main(int argc, char **argv)
 {
-    Ent ents[] = {E(k_add), E(k_sub), E(k_and), E(k_xor), E(k_lshr), E(k_lshl), E(k_mov), E(k_cndmask), E(k_bitop3), E(k_add3),
+    Ent ents[] = {E(k2_or), E(k2_ashr), E(k2_lshl1), E(k2_subrev), E(k2_not), E(k2_min), E(k2_and_or), E(k2_or3), E(k2_bfi),
+                  E(k2_add_lshl), E(k2_mul24), E(k2_add_co), E(k2_sub_co), E(k2_addc_vcc), E(k2_addc_sgpr), E(k2_cndmask_vcc),
+                  E(k2_cndmask_sgpr), E(k2_cndmask_e32), E(k2_cmp_sgpr), E(k2_alt_cmp_cndmask), E(k2_alt_cmpsgpr_cndmask),
+                  E(k2_alt_add_cndmask), E(k2_mov_sgpr), E(k2_add_sgpr), E(k2_max3_sgpr), E(k2_pk_sub_sgpr), E(k2_fmac),
+                  E(k2_mul_f32), E(k2_add_f32), E(k2_xad), E(k2_lshl_or), E(k2_run1_add_max3), E(k2_run2_add_max3),
+                  E(k2_run4_add_max3), E(k2_run8_add_max3), E(k2_run12_4_add_max3), {"k2_run16_16_add_max3", k2_run16_16_add_max3, 32.0}, {"k2_run48_16_add_max3", k2_run48_16_add_max3, 64.0},
+                  {"k2_run16_48_add_max3", k2_run16_48_add_max3, 64.0}, E(k2_cmp_cnd3), E(k2_run2_add_cnd), E(k2_run4_add_cnd), E(k2_mix2_1_add_max3), E(k2_run2_add_cmp), E(k2_run2_and_perm),
+                  E(k2_run2_sub_mad24), E(k2_run2_add_dpp), E(k2_run4_add_lshl_add),
+                  E(k_add), E(k_sub), E(k_and), E(k_xor), E(k_lshr), E(k_lshl), E(k_mov), E(k_cndmask), E(k_bitop3), E(k_add3),
                   E(k_lshl_add), E(k_max3), E(k_max), E(k_mad24), E(k_mul_lo), E(k_cmp), E(k_perm), E(k_alignbit), E(k_bfe),
                   E(k_bcnt), E(k_dot4), E(k_lerp), E(k_sad_u8), E(k_pk_add16), E(k_pk_max16), E(k_pk_lshr16), E(k_pk_mad16),
                   E(k_dpp_mov), E(k_dpp_add), E(k_sdwa_lshl), E(k_sdwa_add), E(k_sdwa_and), E(k_cvt_ub), E(k_fma), E(k_add_u16),

@@ -101,6 +101,26 @@ def test_frames_shorter_than_the_blur_reach(gpu, oracle, preset, h, w):
         check_moments(res[r], exp["moments"][r])
 
 
+@pytest.mark.parametrize("w", [1, 2, 3])
+def test_narrow_tall_frames_with_eight_ranges(oracle, w):
+    """A context sized for frames narrower than 4 px: the inRange BIT planes (4 bytes per row and range) are larger than
+    the byte planes (w bytes per row and range) there, and the slot's plane buffer must hold them."""
+    h = 3000
+    ranges = [((10 * r, 0, 0), (10 * r + 60, 256, 256)) for r in range(8)]
+    f = np.random.default_rng(7 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    p = PRESETS["polygon_path"]
+    with ip.ImgProc(w, h, n_slots=1) as g:
+        g.set_pipeline(**p)
+        g.set_ranges(ranges)
+        res = g.process(f)
+        masks = [g.fetch_stage(0, L.STAGE_MASK, r) for r in range(8)]
+    exp = oracle.chain(f, pre_blur_k=p["pre_blur_k"], post_blur_k=p["post_blur_k"], morph=morph_tuples(p["morph"]),
+                       ranges=ranges, stages=False)
+    for r in range(8):
+        assert (masks[r] == exp["mask"][r]).all(), (w, r)
+        check_moments(res[r], exp["moments"][r])
+
+
 def test_two_contexts_two_threads(oracle):
     """Different contexts are independent and may be driven from different threads (here: both on device 0)."""
     jobs = [("baseline", 320, 200, 51), ("polygon_path", 256, 160, 52)]

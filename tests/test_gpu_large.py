@@ -195,7 +195,15 @@ def test_submit_pinned_skips_the_staging_copy(oracle, padded, preset):
             assert (g.fetch_stage(0, L.STAGE_HSV) == oracle.bgr2hsv(oracle.gaussian_blur(np.ascontiguousarray(views[2]), 3)
                                                                      if preset == "polygon_path" else np.ascontiguousarray(views[2]))).all()
             f4 = views[4].copy()  # before the page-locked block goes away
+            # host_free refuses while views of the block are alive (they would dangle: round 2's segfault), then frees
+            with pytest.raises(ip.pipeline.ImgProcError) as ei:
+                g.host_free(pinned)
+            status, ei = ei.value.status, None
+            assert status == L.ESTATE
+            with pytest.raises(ip.pipeline.ImgProcError):
+                g.host_free(views[0])  # a view is not the array host_alloc handed out
         finally:
+            views = f = ei = None  # ei's traceback holds host_free's frame, hence the array
             g.host_free(pinned)
     exp = oracle.chain(f4, pre_blur_k=kw.get("pre_blur_k", 0), post_blur_k=5, morph=morph_tuples(kw["morph"]), ranges=[DEFAULT_RANGE],
                        stages=False)
