@@ -41,6 +41,22 @@ MORPH_POSE_ESTIMATE = [E(3)] * 2 + [D(8)] * 2 + [E(3)] * 2  # pose_estimate.cpp:
 MORPH_BASELINE = [E(3), D(3)]
 
 
+def _array_over(address: int, nbytes: int, shape, dtype):
+    """(array, owner): a numpy array of `shape` over raw memory, and the object every view of it refers to as its base
+    (numpy collapses base chains to that owner, so its reference count tells whether views are alive)."""
+    buf = (C.c_uint8 * nbytes).from_address(address)
+    owner = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape)))
+    return owner.reshape(shape), owner
+
+
+def _owner_refs(ent) -> int:
+    """Reference count of a pinned array's owner object (ent = [address, array, owner, count with no view alive]): every
+    live view of the array adds one.  Always read through this one function, so the references of the call itself cancel."""
+    import sys
+
+    return sys.getrefcount(ent[2])
+
+
 def _moments_to_dict(m: L.Moments) -> dict:
     return {k: getattr(m, k) for k in ("m00", "m10", "m01", "m20", "m11", "m02", "cx", "cy", "theta", "found")}
 
@@ -63,8 +79,8 @@ class ImgProc:
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
             # page-locked arrays still out (host_alloc without host_free) go with the context: after close() they dangle
-            for p, _ in list(getattr(self, "_pinned", {}).values()):
-                self.lib.imgproc_host_free(self._ctx, p)
+            for ent in list(getattr(self, "_pinned", {}).values()):
+                self.lib.imgproc_host_free(self._ctx, ent[0])
             self._pinned = {}
             self.lib.imgproc_destroy(self._ctx)
             self._ctx = C.c_void_p()
@@ -148,34 +164,30 @@ class ImgProc:
         """A numpy array over page-locked host memory; release with host_free(arr).  The array does NOT own the memory:
         after host_free(arr) (or close()) the array and every view / slice of it point at freed pages, and touching
         one is a use-after-free (a segmentation fault, as gpurun_out/pinned.log of round 2 shows).  Copy what is
-        needed (`arr[i].copy()`) and drop the views before host_free; host_free refuses while it can see other
-        references to the array."""
+        needed (`arr[i].copy()`) and drop the views before host_free; host_free refuses while views are alive."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = C.c_void_p()
         self._chk(self.lib.imgproc_host_alloc(self._ctx, max(n, 1), C.byref(p)), "imgproc_host_alloc")
-        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
-        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        import weakref
-
+        ent = [p.value, *_array_over(p.value, max(n, 1), shape, dtype), 0]
+        ent[3] = _owner_refs(ent)  # with no view alive: host_free compares against it through the same call
         self._pinned = getattr(self, "_pinned", {})
-        self._pinned[arr.ctypes.data] = (p.value, weakref.ref(arr))  # the array itself, not a view that starts at its address
-        return arr
+        self._pinned[id(ent[1])] = ent
+        return ent[1]
 
     def host_free(self, arr: np.ndarray, force: bool = False):
-        """Releases a host_alloc array.  Views of it (`arr[i]`, reshapes) keep a reference to `arr`; while any is alive
-        besides the caller's own name for the array the call raises ImgProcError(ESTATE) instead of leaving them
-        dangling (force=True frees anyway)."""
-        import sys
-
+        """Releases a host_alloc array.  Every view of it (`arr[i]`, slices, reshapes) keeps a reference to the array's
+        owner object; while any is alive the call raises ImgProcError(ESTATE) instead of leaving it dangling
+        (force=True frees anyway).  Only the array host_alloc returned is accepted, not a view of it (EINVAL)."""
         pinned = getattr(self, "_pinned", {})
-        if arr.ctypes.data not in pinned or pinned[arr.ctypes.data][1]() is not arr:
+        ent = pinned.get(id(arr))
+        if ent is None or ent[1] is not arr:
             raise ImgProcError(L.EINVAL, "host_free", "not an array handed out by host_alloc (a view of one?)")
-        # 3 = the caller's name, this parameter, getrefcount's own argument
-        if not force and sys.getrefcount(arr) > 3:
-            raise ImgProcError(L.ESTATE, "host_free", f"{sys.getrefcount(arr) - 3} other reference(s) to the array are alive "
-                               "(views, slices, containers): drop them first, or pass force=True")
-        p = pinned.pop(arr.ctypes.data)[0]
-        self._chk(self.lib.imgproc_host_free(self._ctx, p), "imgproc_host_free")
+        n_views = _owner_refs(ent) - ent[3]
+        if not force and n_views:
+            raise ImgProcError(L.ESTATE, "host_free", f"{n_views} view(s) of the array are alive (slices, reshapes, containers "
+                               "holding them): drop them first, or pass force=True")
+        del pinned[id(arr)]
+        self._chk(self.lib.imgproc_host_free(self._ctx, ent[0]), "imgproc_host_free")
 
     def wait(self, slot: int):
         r = L.Result()

@@ -73,3 +73,30 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(ip.ImgProcError) as e:
         ip.ImgProc(64, 64)
     assert e.value.status in (L.ENODEV, L.EHIP)
+
+
+def test_pinned_array_view_accounting():
+    """ImgProc.host_free refuses to free a page-locked block while views of it are alive: the bookkeeping behind that
+    (views refer to the array's owner object, whatever they were sliced from), on plain host memory."""
+    import ctypes as C
+
+    from image_processing_amd.pipeline import _array_over, _owner_refs
+
+    raw = (C.c_uint8 * 600)()
+
+    def alloc():
+        ent = [C.addressof(raw), *_array_over(C.addressof(raw), 600, (2, 10, 10, 3), np.uint8), 0]
+        ent[3] = _owner_refs(ent)
+        return ent
+
+    ent = alloc()
+    arr = ent[1]
+    assert arr.shape == (2, 10, 10, 3) and arr.ctypes.data == C.addressof(raw)
+    live = lambda: _owner_refs(ent) - ent[3]  # noqa: E731
+    assert live() == 0
+    v = arr[0, :, :5]  # starts at the array's own address: must still count as a view, not as the array
+    assert v.ctypes.data == arr.ctypes.data and live() == 1
+    more = [arr[1], arr.reshape(-1), v[2:]]
+    assert live() == 4
+    del v, more
+    assert live() == 0
