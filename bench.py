@@ -254,6 +254,13 @@ def run_rank(args) -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dry = os.environ.get("BENCH_DRY_RUN") == "1"  # CPU rehearsal of the launch / rendezvous / relay logic: no GPU work
 
+    # before anything touches the GPU: this rank's threads (the library's staging-copy helpers included) and every
+    # page-locked buffer allocated below stay on the NUMA node its GPU hangs off
+    from image_processing_amd.shard import pin_to_gpu_numa
+
+    gpu_index = 0 if os.environ.get("BENCH_ALL_RANKS_ON_GPU0") == "1" else local_rank
+    numa = pin_to_gpu_numa(gpu_index, sysfs=os.environ.get("BENCH_SYSFS_ROOT", "/sys")) if not args.no_numa else {"pinned": False, "skipped": True}
+
     import torch
 
     dist = None
@@ -316,7 +323,10 @@ def run_rank(args) -> None:
             print(json.dumps({"metric": cfg["metric"], "value": frames_per_step_total * args.steps / dt, "unit": "frames/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                               "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "u8",
-                              "data": "dry run: no GPU work", "config": {"workload": cfg["workload"], "dry_run": True}}), flush=True)
+                              "data": "dry run: no GPU work", "config": {"workload": cfg["workload"], "dry_run": True},
+                              "numa": dict(numa, affinity_now=sorted(os.sched_getaffinity(0))),
+                              **({"streamed": {"value": frames_per_step_total / dt, "unit": "frames/s", "pcie_gbps": 0.0, "slots": 3,
+                                               "frames": frames_per_step_total, "dry_run": True}} if args.streamed else {})}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -412,6 +422,9 @@ def run_rank(args) -> None:
     gather_ms = (time.perf_counter() - t_g) * 1e3
     n_found = int((centroids(gathered)[:, 0, 0] >= 0).sum()) if rank == 0 else 0
 
+    streamed = None
+    if args.streamed and cn == 3:
+        streamed = streamed_rank_leg(cfg, frames, batches, local, a, local_rank, world, dist, nb)
     checked = False
     if args.check and rank == 0:
         # one frame of the last batch against the oracle, after the timed region (every run, unless --no-check): the
@@ -493,6 +506,9 @@ def run_rank(args) -> None:
             "roofline": roof,
             "achieved_gbps_whole_job": fps * algo_bytes / 1e9,
         }
+        out["numa"] = numa
+        if streamed is not None:
+            out["streamed"] = streamed
         if args.config == "c3" and world == 1 and not args.no_streamed:
             out["streamed"] = streamed_leg(cfg, base_np, local_rank)
         if world == 1 and not args.no_cpu_baseline:
@@ -502,6 +518,76 @@ def run_rank(args) -> None:
     g.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def streamed_rank_leg(cfg: dict, frames_dev, batches, local, first_frame: int, device: int, world: int, dist, nb: int, slots: int = 3) -> dict:
+    """The streamed mode of a sharded configuration (SURVEY §8d "two reported modes", §8e): every rank feeds ITS block of
+    the step's frames from page-locked host memory through imgproc_submit_pinned (`slots` slots, each on its own stream:
+    upload of frame k+1 overlaps the chain kernel of frame k), moments back per frame.  PCIe-bound; timed like the main
+    leg (barrier, max over ranks) and reported beside the device-resident `value`, never as it.  The per-frame m00 / m10 /
+    m01 must equal the device-resident leg's for the same stream frame ids."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import image_processing_amd as ip
+    from image_processing_amd import _lib as L
+
+    W, H = cfg["w"], cfg["h"]
+    pool_n = frames_dev.shape[0]
+    n_local = sum(n for _, n, _ in batches[:nb])
+    with ip.ImgProc(W, H, device=device, n_slots=slots) as g:
+        g.set_pipeline(encoding=cfg["enc"], **cfg["pipe"])
+        g.set_ranges(cfg["ranges"])
+        pin = g.host_alloc((pool_n, H, W, 3))  # the same pool of frames, page-locked, on this rank's NUMA node
+        pin[:] = frames_dev.cpu().numpy()
+        addr0, fstride, rstride = pin.ctypes.data, pin.strides[0], pin.strides[1]
+        order = [(off + i) for off, n, _ in batches[:nb] for i in range(n)]  # pool index of every frame of my block, in stream order
+        res = (L.Result * max(n_local, 1))()
+        lib, ctx = g.lib, g._ctx
+
+        def run_all(count):
+            # submit / wait pipeline over `count` frames: wait for slot s just before it is reused, then drain
+            waited = 0
+            for i in range(count):
+                if i >= slots:
+                    rc = lib.imgproc_wait(ctx, i % slots, C.byref(res[i - slots]))
+                    assert rc == 0, lib.imgproc_last_error(ctx)
+                    waited += 1
+                rc = lib.imgproc_submit_pinned(ctx, i % slots, addr0 + order[i] * fstride, rstride, W, H)
+                assert rc == 0, lib.imgproc_last_error(ctx)
+            for i in range(waited, count):
+                rc = lib.imgproc_wait(ctx, i % slots, C.byref(res[i]))
+                assert rc == 0, lib.imgproc_last_error(ctx)
+
+        run_all(min(n_local, 32))  # warm-up
+        g.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        run_all(n_local)
+        g.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # same frames, same chain: the streamed moments are the device-resident leg's (last step), frame by frame
+        nr = len(cfg["ranges"])
+        for i in range(n_local):
+            for r in range(nr):
+                m = res[i].r[r]
+                assert (m.m00, m.m10, m.m01) == tuple(int(v) for v in local[i, r]), f"streamed frame {first_frame + i} != device-resident leg"
+        del res
+        g.host_free(pin)
+    total = cfg.get("stream", pool_n * world) if cfg["scaling"] == "strong" else n_local * world
+    fb = W * H * 3
+    return {"value": total / dt, "unit": "frames/s", "pcie_gbps": total * fb / dt / 1e9, "pcie_gbps_per_gpu": total * fb / dt / 1e9 / world,
+            "slots": slots, "frames": total, "frames_per_rank": n_local, "seconds": dt,
+            "note": "every rank streams its block of the step's frames from page-locked host memory through imgproc_submit_pinned "
+                    "(3 slots, H2D of frame k+1 overlaps the chain kernel of frame k), per-frame moments back; barrier + max over "
+                    "ranks; per-frame moments equal the device-resident leg's (asserted); PCIe Gen5 x16 practical peak ~55 GB/s per GPU"}
 
 
 def streamed_leg(cfg: dict, base_np, device: int, n: int = 96, slots: int = 3) -> dict:
@@ -570,6 +656,10 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true", help="c3: skip the streamed (PCIe) leg")
     ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")
+    ap.add_argument("--streamed", action="store_true",
+                    help="BGR configurations (c4: the sharded stream): add the streamed leg -- every rank feeds its frames from "
+                         "page-locked host memory through imgproc_submit_pinned; reported under `streamed`, never as `value`")
+    ap.add_argument("--no-numa", action="store_true", help="leave the CPU affinity alone (default: pin each rank to its GPU's NUMA node)")
     ap.add_argument("--no-check", dest="check", action="store_false",
                     help="skip the oracle check of one frame of the last batch (it runs after the timed region by default)")
     ap.add_argument("--check", dest="check", action="store_true", help="(default) verify one frame of the last batch against the oracle")
@@ -588,6 +678,9 @@ def main() -> int:
         argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config]
         argv += ["--no-cpu-baseline"] if args.no_cpu_baseline else []
         argv += ["--unfused"] if args.unfused else []
+        argv += ["--streamed"] if args.streamed else []
+        argv += ["--no-numa"] if args.no_numa else []
+        argv += ["--no-streamed"] if args.no_streamed else []
         argv += [] if args.check else ["--no-check"]
         return spawn_ranks(args.gpus, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))

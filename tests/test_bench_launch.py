@@ -50,3 +50,59 @@ def test_failed_rank_fails_the_parent():
     p = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "c2", env_extra={"BENCH_DRY_RUN": "0", "HIP_VISIBLE_DEVICES": "",
                                                                                                "CUDA_VISIBLE_DEVICES": ""})
     assert p.returncode != 0
+
+
+def fake_sysfs(root, gpus):
+    """A sysfs tree with one CPU node and `gpus` = [(pci address, numa node)] as KFD GPU nodes, two NUMA nodes of CPUs."""
+    def put(path, text):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+
+    put(os.path.join(root, "class/kfd/kfd/topology/nodes/0/properties"), "cpu_cores_count 8\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (addr, node) in enumerate(gpus):
+        dom, bus, devfn = addr.split(":")
+        dev, fn = devfn.split(".")
+        loc = (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn)
+        put(os.path.join(root, f"class/kfd/kfd/topology/nodes/{i + 1}/properties"),
+            f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {loc}\ndomain {int(dom, 16)}\n")
+        put(os.path.join(root, "bus/pci/devices", addr, "numa_node"), f"{node}\n")
+    cpus = sorted(os.sched_getaffinity(0))
+    half = max(1, len(cpus) // 2)
+    put(os.path.join(root, "devices/system/node/node0/cpulist"), ",".join(map(str, cpus[:half])) + "\n")
+    put(os.path.join(root, "devices/system/node/node1/cpulist"), f"{cpus[half] if len(cpus) > half else cpus[0]}-{cpus[-1]}\n")
+    return cpus[:half], cpus[half:] or cpus[:1]
+
+
+def test_pin_to_gpu_numa(tmp_path, monkeypatch):
+    from image_processing_amd.shard import gpu_pci_addresses, pin_to_gpu_numa
+
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    root = str(tmp_path)
+    n0, n1 = fake_sysfs(root, [("0000:05:00.0", 0), ("0000:85:00.0", 1), ("0001:c5:00.0", -1)])
+    assert gpu_pci_addresses(root) == ["0000:05:00.0", "0000:85:00.0", "0001:c5:00.0"]
+    calls = []
+    info = pin_to_gpu_numa(1, sysfs=root, setaffinity=lambda pid, cpus: calls.append((pid, sorted(cpus))))
+    assert info == {"numa_node": 1, "cpus": len(n1), "pci": "0000:85:00.0", "pinned": True} and calls == [(0, n1)]
+    # numa_node -1, a rank beyond the GPUs, no sysfs at all: nothing is touched, nothing raises
+    for rank, sysfs in ((2, root), (7, root), (0, os.path.join(root, "nowhere"))):
+        calls.clear()
+        assert pin_to_gpu_numa(rank, sysfs=sysfs, setaffinity=lambda *a: calls.append(a))["pinned"] is False and not calls
+    # a visible-devices list maps the rank to its entry
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")
+    assert pin_to_gpu_numa(0, sysfs=root, setaffinity=lambda *a: None)["pci"] == "0000:85:00.0"
+
+
+def test_streamed_leg_and_numa_placement_of_two_ranks(tmp_path):
+    """`--config c4 --streamed --gpus 2` (dry run): each rank pins itself to its GPU's NUMA node before anything else, and
+    the line carries the streamed leg's keys beside the device-resident value."""
+    n0, n1 = fake_sysfs(str(tmp_path), [("0000:05:00.0", 0), ("0000:85:00.0", 1)])
+    p = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "c4", "--streamed", env_extra={"BENCH_SYSFS_ROOT": str(tmp_path)})
+    assert p.returncode == 0, p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["numa"]["pinned"] is True and out["numa"]["numa_node"] == 0 and out["numa"]["affinity_now"] == n0  # rank 0's line
+    assert {"value", "unit", "pcie_gbps", "slots", "frames"} <= set(out["streamed"]) and out["streamed"]["frames"] == 4096
+    q = run_bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "c4", "--streamed", "--no-numa",
+                  env_extra={"BENCH_SYSFS_ROOT": str(tmp_path)})
+    assert q.returncode == 0 and json.loads(q.stdout.strip().splitlines()[-1])["numa"]["pinned"] is False
