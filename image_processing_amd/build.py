@@ -9,12 +9,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libimgproc_hip.so")
 SOURCES = ["api.hip", "kernels.hip", "fused.hip", "fused_inst_plain_small.hip", "fused_inst_plain_large.hip",
-           "fused_inst_bayer_small.hip", "fused_inst_bayer_large.hip", "morphbits.hip", "gauss.hip", "gauss_mfma.hip"]
-HEADERS = ["kernels.h", "fused.h", "fused_kernel.hpp", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
+           "fused_inst_bayer_small.hip", "fused_inst_bayer_large.hip", "morphbits.hip", "gauss.hip", "gauss_mfma.hip", "gauss_fused.hip"]
+HEADERS = ["kernels.h", "fused.h", "fused_kernel.hpp", "hsv_px.hpp", "morphbits.h", os.path.join("..", "..", "include", "imgproc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread"]
 # per-source extras.  gauss_mfma.hip: MFMA results in VGPRs (the allocator's default put the accumulators into AGPRs and paid
 # 48 v_accvgpr_read per 16-row block, a quarter of the kernel's vector instructions, to get them back out)
-EXTRA_FLAGS = {"gauss_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"gauss_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gauss_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 OBJDIR = os.path.join(LIBDIR, "obj")

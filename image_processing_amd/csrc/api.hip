@@ -400,6 +400,14 @@ int alloc_slot(imgproc_ctx *c, Slot &s, bool staging = true)
 // to the caller, who runs it for several frames in one launch.
 static bool bit_plane_tail(const Plan &p) { return p.bm_ok && !p.pipe.force_unfused && !p.pipe.keep_stages; }
 
+// Long post-HSV Gaussian (k = 7..15) + bit-plane tail: [HSV,] blur and inRange run as ONE kernel (gauss_fused.hip), on the
+// BGR / RGB image (`hsv_in`) or on an HSV image a stage kernel produced.  IMGPROC_GAUSS_FUSED=0 keeps the three stage kernels.
+static bool gauss_fused_wanted(const Plan &p)
+{
+    static const bool off = [] { const char *e = getenv("IMGPROC_GAUSS_FUSED"); return e && e[0] == '0'; }();
+    return !off && bit_plane_tail(p) && p.pipe.post_blur_k >= 7 && p.pipe.post_blur_k <= 15;
+}
+
 int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, int w, int h, u8 *d_masks_out,
                 unsigned long long *d_mom, int *launches, hipStream_t st, int upto = IMGPROC_STAGE_MASK,
                 uint32_t *bits_out = nullptr)
@@ -427,6 +435,19 @@ int run_unfused(imgproc_ctx *c, Slot &s, const u8 *d_frame, size_t row_stride, i
     s.bgr_ptr = cur;  // may be the caller's frame itself (then the row stride is the caller's)
     s.bgr_stride = cur_stride;
     if (upto == IMGPROC_STAGE_BGR) return 0;
+    if (upto > IMGPROC_STAGE_THRESH && gauss_fused_wanted(p) && ipk::gauss_fused_ok(cur, 0, cur_stride, w, h, p.post, p.bounds)) {
+        // HSV + long Gaussian + inRange -> bit planes in one kernel, then (unless the caller collects planes of several
+        // frames) the whole morph list + moments + final masks in one more
+        uint32_t *bits = bits_out ? bits_out : reinterpret_cast<uint32_t *>(s.d_thresh);
+        HIPCHK(c, ipk::launch_gauss_fused(cur, 0, cur_stride, bits, w, h, 1, p.post, p.bounds, bidx, c->d_tables, st));
+        nl++;
+        if (!bits_out) {
+            HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, nullptr, d_masks_out, d_mom, w, h, p.bounds.n, p.pipe.second_order, st, bits));
+            nl++;
+        }
+        if (launches) *launches += nl;
+        return 0;
+    }
     HIPCHK(c, ipk::launch_bgr2hsv(cur, cur_stride, s.d_a, t3, w, h, bidx, c->d_tables, st));
     nl++;
     s.hsv_ptr = s.d_a;
@@ -1043,8 +1064,6 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
                                        p.pipe.second_order, c->stream, bits));
         bt.launches = 2;
     } else if (bit_plane_tail(p)) {
-        rc = ensure_work(c);
-        if (rc) return rc;
         // stage kernels per frame up to the inRange bit planes, then the bit-plane morphology of a whole group of frames in
         // one launch (planes = frames x ranges): at one 8K frame it has too few independent columns to fill the chip
         const size_t per_frame = (size_t)nr * h * ipm::bit_words(w) * 4;
@@ -1060,9 +1079,21 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
             c->thresh_batch_bytes = need;
         }
         uint32_t *bits = reinterpret_cast<uint32_t *>(c->d_thresh_batch);
+        // frames that need no demosaic / pre-blur go through the fused HSV + Gaussian + inRange kernel a whole group at a time
+        const bool group_fused = gauss_fused_wanted(p) && p.pipe.encoding != IMGPROC_ENC_BAYER_RGGB8 && p.pipe.pre_blur_k <= 1 &&
+                                 ipk::gauss_fused_ok((const u8 *)d_frames, frame_stride, row_stride, w, h, p.post, p.bounds);
+        if (!group_fused) {  // the stage kernels work in the context's own planes
+            rc = ensure_work(c);
+            if (rc) return rc;
+        }
         for (int g0 = 0; g0 < n; g0 += group) {
             const int gn = std::min(group, n - g0);
-            for (int i = 0; i < gn; i++) {
+            if (group_fused) {
+                HIPCHK(c, ipk::launch_gauss_fused((const u8 *)d_frames + (size_t)g0 * frame_stride, frame_stride, row_stride, bits, w, h, gn,
+                                                  p.post, p.bounds, p.pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0, c->d_tables, c->stream));
+                bt.launches++;
+            }
+            for (int i = 0; i < gn && !group_fused; i++) {
                 rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)(g0 + i) * frame_stride, row_stride, w, h, nullptr, nullptr,
                                  &bt.launches, c->stream, IMGPROC_STAGE_MASK, bits + (size_t)i * (per_frame / 4));
                 if (rc) return rc;

@@ -45,6 +45,11 @@ hipError_t launch_in_range(const u8 *src, size_t sstride, u8 *dst, size_t dstrid
 // inRange for 1..8 ranges with bit planes out: dst[range][h][(w+31)/32] words, bit i of word j = pixel 32 j + i
 hipError_t launch_in_range_bits(const u8 *src, size_t sstride, uint32_t *dst, int w, int h, const Bounds &b,
                                 hipStream_t stream);
+// BGR2HSV + GaussianBlur(k = 7..15) + inRange in one kernel, bit planes out (gauss_fused.hip): n frames of BGR (bidx 0) or
+// RGB (bidx 2) at src + i * frame_stride -> bits[n][b.n][h][(w+31)/32]
+bool gauss_fused_ok(const u8 *src, size_t frame_stride, size_t sstride, int w, int h, const Taps &taps, const Bounds &b);
+hipError_t launch_gauss_fused(const u8 *src, size_t frame_stride, size_t sstride, uint32_t *bits, int w, int h, int n,
+                              const Taps &taps, const Bounds &b, int bidx, const int *d_hsv_tables, hipStream_t stream);
 hipError_t launch_morph(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int kind,
                         const Element &e, hipStream_t stream);
 // adds into d_m[6] (u64: m00 m10 m01 m20 m11 m02); caller zeroes

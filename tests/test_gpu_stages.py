@@ -155,3 +155,65 @@ def test_gaussian_long_kernels_on_matrix_cores(oracle, monkeypatch, hw, cn, k):
         other = g.GaussianBlur(img, k)
     assert (got == exp).all()
     assert (other == exp).all()
+
+
+# ---- the fused HSV + long Gaussian + inRange kernel (gauss_fused.hip): bit planes pinned to the oracle ----------------
+FUSED_RANGES8 = [((20 * i, 30, 40), (20 * i + 25, 256, 230)) for i in range(7)] + [((0, 0, 0), (256, 90, 256))]
+
+
+@pytest.mark.parametrize("hw,k,rgb,nr", [((700, 2052), 15, False, 8), ((33, 97), 15, True, 8), ((1, 1), 15, False, 1), ((5, 40), 7, False, 3),
+                                         ((17, 31), 9, True, 2), ((70, 36), 11, False, 5), ((49, 64), 13, False, 8), ((16, 32), 15, False, 4)])
+def test_fused_hsv_gaussian_inrange_bit_planes(oracle, monkeypatch, hw, k, rgb, nr):
+    """inRange(GaussianBlur_k(BGR2HSV(frame))) for 1..8 ranges through the fused kernel.  The morphology list is one erode
+    with a 1x1 element (the identity), so the final mask IS the kernel's bit plane: compared with the oracle's inRange of
+    its own blur, and with the three stage kernels (IMGPROC_GAUSS_FUSED=0 is read once per process, so the stage path is
+    taken by force_unfused).  Sizes: many 32-pixel strips and 16-row blocks (2052x700, 8 ranges), single pixel, frames
+    narrower than the kernel's reach, widths that end inside a word."""
+    h, w = hw
+    f = np.random.default_rng(1000 * h + w + k).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    f[h // 4: h - h // 4, w // 5: w - w // 5] //= 2  # a darker block: V bounds cut through it after the blur
+    ranges = FUSED_RANGES8[8 - nr:]
+    ident = [ip.E(1)]
+    with ip.ImgProc(w, h, n_slots=1) as g:
+        g.set_pipeline(encoding=L.ENC_RGB8 if rgb else L.ENC_BGR8, post_blur_k=k, morph=ident)
+        g.set_ranges(ranges)
+        assert "bit-plane" in g.plan
+        res = g.process(f)
+        got = [g.fetch_stage(0, L.STAGE_MASK, r) for r in range(nr)]
+        g.set_pipeline(encoding=L.ENC_RGB8 if rgb else L.ENC_BGR8, post_blur_k=k, morph=ident, force_unfused=True)
+        g.process(f)
+        stage = [g.fetch_stage(0, L.STAGE_MASK, r) for r in range(nr)]
+    bgr = f[:, :, ::-1] if rgb else f
+    blur = oracle.gaussian_blur(oracle.bgr2hsv(np.ascontiguousarray(bgr)), k)
+    for r in range(nr):
+        exp = oracle.in_range(blur, ranges[r][0], ranges[r][1])
+        assert (got[r] == exp).all(), (hw, k, r, int((got[r] != exp).sum()))
+        assert (stage[r] == exp).all()
+        assert res[r]["m00"] == int((exp != 0).sum())
+
+
+def test_fused_hsv_gaussian_inrange_batch(oracle):
+    """The same kernel with several frames in one launch (device batch, padded row pitch, frame stride with a gap)."""
+    h, w, n, k = 83, 130, 3, 15
+    pitch, fstride = w * 3 + 8, h * (w * 3 + 8) + 64
+    rng = np.random.default_rng(5)
+    buf = rng.integers(0, 256, (n, fstride), dtype=np.uint8)
+    frames = np.stack([buf[i, : h * pitch].reshape(h, pitch)[:, : w * 3].reshape(h, w, 3) for i in range(n)])
+    ranges = FUSED_RANGES8
+    with ip.ImgProc(w, h, n_slots=1, max_batch=n) as g:
+        g.set_pipeline(post_blur_k=k, morph=[ip.E(1)])
+        g.set_ranges(ranges)
+        d_in, d_out = g.dev_alloc(buf.nbytes), g.dev_alloc(n * 8 * w * h)
+        try:
+            g.dev_upload(d_in, buf)
+            res = g.process_batch_device(d_in, fstride, pitch, w, h, n, d_out)
+            masks = g.dev_download(d_out, (n, 8, h, w))
+        finally:
+            g.dev_free(d_in)
+            g.dev_free(d_out)
+    for i in range(n):
+        blur = oracle.gaussian_blur(oracle.bgr2hsv(np.ascontiguousarray(frames[i])), k)
+        for r in range(8):
+            exp = oracle.in_range(blur, ranges[r][0], ranges[r][1])
+            assert (masks[i, r] == exp).all(), (i, r)
+            assert res[i][r]["m00"] == int((exp != 0).sum())
