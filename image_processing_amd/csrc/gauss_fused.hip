@@ -335,10 +335,12 @@ hipError_t launch_gauss_fused(const u8 *src, size_t frame_stride, size_t sstride
     a.b = b;
     a.nstrips = a.words;
     a.nblocks = (h + 15) / 16;
-    // every segment runs two extra blocks (the one above, the one below); segments are sized so that the launch has
-    // about 12 k waves (as k_gaussian_mfma: latency-bound steps at the 3 waves per SIMD the LDS allows), at least 4 blocks each
+    // every segment runs two extra blocks (the one above, the one below), yet short segments win: a block's steps are a
+    // chain of dependent LDS / MFMA phases at the 3 waves per SIMD the LDS allows, and a finer grain evens out the rounds.
+    // Measured at 4 frames of 7680x4320 (960 strip columns): 8 segments per column 0.433 ms, 12 0.397, 16 0.375, 23 0.360,
+    // 34 0.362, 46 0.371, 68 0.416 -> about 24 k waves per launch, at least 4 blocks per segment
     const long long cols = (long long)a.nstrips * n;
-    int nsegs = (int)std::max<long long>(1, std::min<long long>((12288 + cols - 1) / cols, (a.nblocks + 3) / 4));
+    int nsegs = (int)std::max<long long>(1, std::min<long long>((24576 + cols - 1) / cols, (a.nblocks + 3) / 4));
     if (const char *e = getenv("IMGPROC_GAUSS_SEGS")) nsegs = std::max(1, std::min(atoi(e), a.nblocks));
     a.seg_blocks = (a.nblocks + nsegs - 1) / nsegs;
     a.nsegs = (a.nblocks + a.seg_blocks - 1) / a.seg_blocks;

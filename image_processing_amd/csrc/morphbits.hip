@@ -526,17 +526,25 @@ __global__ __launch_bounds__(256) void k_bitstrip(const StripArgs a)
         return ok ? src[(size_t)r * a.twords] : 0u;
     };
     constexpr uint32_t km_first = LIST::get(0).kind ? 0xFFFFFFFFu : 0u, km_last = LIST::get(NG - 1).kind ? 0xFFFFFFFFu : 0u;
-    uint32_t nxt0 = load(r0), nxt1 = load(r0 + 1), nxt2 = load(r0 + 2);
+#ifndef BS_PF
+#define BS_PF 8  // rows of load look-ahead (a register ring).  The plane words come from HBM through a memory system that is
+                 // saturated with this kernel's own mask stores (scripts/ubench/write_bw.hip `like` / `b` / `k`: real loads
+                 // beside the stores cost 28 % of the store rate, cache-hit loads nothing, eight rows ahead give 11 % back);
+                 // measured here: c5 +1.8 % against 3 rows, pp / pe unchanged
+#endif
+    static_assert(BS_PF == 1 || BS_PF == 2 || BS_PF == 4 || BS_PF == 8, "the ring slot (row % BS_PF) must be a constant of the 8x unrolled loop");
+    uint32_t nxt[8];
+#pragma unroll
+    for (int q = 0; q < BS_PF; q++) nxt[q] = load(r0 + q);
     // whole batches of 8 rows (ring slots are register names): the rows a last, partial batch runs beyond the segment are
     // computed and dropped
     for (int ib = 0; ib < n_iter; ib += 8) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int r = r0 + ib + u;
-            const uint32_t in = nxt0;
-            nxt0 = nxt1;
-            nxt1 = nxt2;
-            nxt2 = load(r + 3);
+            // row r sits in ring slot (r - r0) % BS_PF; with BS_PF in {1, 2, 4, 8} the slot is a constant of the unrolled loop
+            const uint32_t in = nxt[u % BS_PF];
+            nxt[u % BS_PF] = load(r + BS_PF);
             uint32_t x = (in ^ km_first) | cinv | ((r >= 0 && r < h) ? 0u : 0xFFFFFFFFu);
             auto group = [&](auto gc) {
                 constexpr int g = decltype(gc)::value;
