@@ -28,6 +28,10 @@
 
 #include <algorithm>
 
+#ifndef IPF_CASCADE
+#define IPF_CASCADE 1  // 5x5 Gaussian as cascaded pair sums (plain adds); 0: the ring / shift-add form (kept for A/B)
+#endif
+
 namespace ipf {
 
 using ipk::u8;
@@ -526,12 +530,32 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 
     // fed row f uses raw/ring slot (f + 8 - 2*LEAD) & 7, so that the main step j = f - 2*LEAD uses slot j & 7
     constexpr int S0 = (8 - 2 * LEAD) & 7;
+    // Vertical 1-4-6-4-1 as four running [1 1] steps down the rows ([1 1]^4 = 1 4 6 4 1): per register and row four plain
+    // v_add_u32 on the previous row's value and the three running sums -- the cheap issue class -- instead of
+    // add-shift, three-input add and multiply-add on a ring of five rows.  State: the previous row and its three sums
+    // (24 registers, against 30 for the ring's five live rows); the first four rows pushed only warm it up.
+    uint32_t cas[4][6];  // [0]: previous row; [1..3]: previous first / second / third sums; H|S of pixels 0..3, then the V pairs
+#pragma unroll
+    for (int i = 0; i < 24; i++) cas[i / 6][i % 6] = 0;
+    auto cascade = [&](const Row &row, uint32_t (&c_hs)[4], uint32_t (&c_v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const uint32_t a = i < 4 ? row.hs[i] : row.v[i - 4];
+            const uint32_t s1 = a + cas[0][i], s2 = s1 + cas[1][i], s3 = s2 + cas[2][i], out = s3 + cas[3][i];
+            cas[0][i] = a; cas[1][i] = s1; cas[2][i] = s2; cas[3][i] = s3;
+            if (i < 4) c_hs[i] = out; else c_v[i - 4] = out;
+        }
+    };
 #pragma unroll
     for (int q = 0; q < PF; q++) load_row((S0 + q) & 7, q);
 #pragma unroll
     for (int q = 0; q < 2 * LEAD; q++) {  // prologue: fill the rings
         load_row((S0 + q + PF) & 7, q + PF);
         convert((S0 + q) & 7, q >= (PRE_K == 3 ? 2 : 0), q);
+        if (POST_K == 5 && IPF_CASCADE && q >= (PRE_K == 3 ? 2 : 0)) {
+            uint32_t d_hs[4], d_v[2];
+            cascade(ring[(S0 + q) & 7], d_hs, d_v);
+        }
     }
 
     const TransposeConsts tc = transpose_consts(lane);  // MODE 2 only
@@ -554,14 +578,18 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
             uint32_t o_hs[4], o_v[2];
             if (POST_K == 5) {
                 uint32_t c_hs[4], c_v[2];
+                if (IPF_CASCADE) {
+                    cascade(ring[rr], c_hs, c_v);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    c_hs[k] = vert5(ring[(rr + 4) & 7].hs[k], ring[(rr + 5) & 7].hs[k], ring[(rr + 6) & 7].hs[k],
-                                    ring[(rr + 7) & 7].hs[k], ring[rr].hs[k]);
+                    for (int k = 0; k < 4; k++)
+                        c_hs[k] = vert5(ring[(rr + 4) & 7].hs[k], ring[(rr + 5) & 7].hs[k], ring[(rr + 6) & 7].hs[k],
+                                        ring[(rr + 7) & 7].hs[k], ring[rr].hs[k]);
 #pragma unroll
-                for (int k = 0; k < 2; k++)
-                    c_v[k] = vert5(ring[(rr + 4) & 7].v[k], ring[(rr + 5) & 7].v[k], ring[(rr + 6) & 7].v[k],
-                                   ring[(rr + 7) & 7].v[k], ring[rr].v[k]);
+                    for (int k = 0; k < 2; k++)
+                        c_v[k] = vert5(ring[(rr + 4) & 7].v[k], ring[(rr + 5) & 7].v[k], ring[(rr + 6) & 7].v[k],
+                                       ring[(rr + 7) & 7].v[k], ring[rr].v[k]);
+                }
                 if (border_strip) {
                     // BORDER_REFLECT_101 at the image's left/right edge: give the halo lane next to the border
                     // lane the mirrored columns, so the DPP fetches below read col -1 = col 1, col -2 = col 2
@@ -573,15 +601,32 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
                     if (lb_halo) { c_hs[2] = a2; c_hs[3] = a1; c_v[1] = asw; }
                     if (rb_halo) { c_hs[0] = b2; c_hs[1] = b1; c_v[0] = bsw; }
                 }
-                const uint32_t l3 = from_left(c_hs[3]), r0 = from_right(c_hs[0]);
                 const uint32_t vl = from_left(c_v[1]), vr = from_right(c_v[0]);
                 const uint32_t m2 = alignbit(c_v[1], c_v[0], 16);  // (V1,V2)
-                // the k-2 / k+2 terms that cross lanes are single-use: written as plain adds so the DPP fetch
-                // folds into the add (v_add_u32_dpp)
-                o_hs[0] = horz5s(add_from_left(c_hs[2], c_hs[2]), l3, c_hs[1], c_hs[0]);
-                o_hs[1] = horz5s(l3 + c_hs[3], c_hs[0], c_hs[2], c_hs[1]);
-                o_hs[2] = horz5s(c_hs[0] + r0, c_hs[1], c_hs[3], c_hs[2]);
-                o_hs[3] = horz5s(add_from_right(c_hs[1], c_hs[1]), c_hs[2], r0, c_hs[3]);
+                if (IPF_CASCADE) {
+                    // horizontal 1-4-6-4-1 of the H|S registers the same way: pair sums p, their pair sums q (1 2 1), theirs r
+                    // (1 3 3 1), out = r[k-1] + r[k]; the terms that cross lanes come with the add (v_add_u32_dpp).
+                    // 16 plain adds + 4 DPP adds against 4 DPP ops + 2 adds + 12 three-input ops
+                    const uint32_t p0 = c_hs[0] + c_hs[1], p1 = c_hs[1] + c_hs[2], p2 = c_hs[2] + c_hs[3];
+                    const uint32_t pm1 = add_from_left(c_hs[3], c_hs[0]);   // c[-1] + c[0]
+                    const uint32_t p3 = add_from_right(c_hs[0], c_hs[3]);   // c[3] + c[4]
+                    const uint32_t q0 = pm1 + p0, q1 = p0 + p1, q2 = p1 + p2, q3 = p2 + p3;
+                    const uint32_t qm1 = add_from_left(p2, pm1);            // p[-2] + p[-1]: lane-1's p2 is c[-2] + c[-1]
+                    const uint32_t q4 = add_from_right(p0, p3);             // p[3] + p[4]: lane+1's p0 is c[4] + c[5]
+                    const uint32_t rm1 = qm1 + q0, r0 = q0 + q1, r1 = q1 + q2, r2 = q2 + q3, r3 = q3 + q4;
+                    o_hs[0] = rm1 + r0;
+                    o_hs[1] = r0 + r1;
+                    o_hs[2] = r1 + r2;
+                    o_hs[3] = r2 + r3;
+                } else {
+                    const uint32_t l3 = from_left(c_hs[3]), r0 = from_right(c_hs[0]);
+                    // the k-2 / k+2 terms that cross lanes are single-use: written as plain adds so the DPP fetch
+                    // folds into the add (v_add_u32_dpp)
+                    o_hs[0] = horz5s(add_from_left(c_hs[2], c_hs[2]), l3, c_hs[1], c_hs[0]);
+                    o_hs[1] = horz5s(l3 + c_hs[3], c_hs[0], c_hs[2], c_hs[1]);
+                    o_hs[2] = horz5s(c_hs[0] + r0, c_hs[1], c_hs[3], c_hs[2]);
+                    o_hs[3] = horz5s(add_from_right(c_hs[1], c_hs[1]), c_hs[2], r0, c_hs[3]);
+                }
                 const uint32_t m1 = alignbit(c_v[0], vl, 16);  // (V-1,V0)
                 const uint32_t m3 = alignbit(vr, c_v[1], 16);  // (V3,V4)
                 o_v[0] = horz5s(vl + c_v[1], m1, m2, c_v[0]);
