@@ -137,6 +137,11 @@ int main()
         run("loads + 16-byte stores of 8 rows, 6 waves/SIMD", k_traffic16<true, 6>, 100, K, px * 4);
         run("16-byte stores of 8 rows only", k_traffic16<false, 6>, 100, K, px * 1);
     }
+    for (int K : {128, 168}) {  // how well do arithmetic and traffic overlap at 4 / 6 / 8 waves per SIMD?
+        run("loads + stores, 4 waves/SIMD", k_traffic<true, true, 4>, 100, K, px * 4);
+        run("loads + stores, 8 waves/SIMD", k_traffic<true, true, 8>, 100, K, px * 4);
+        run("no memory, 8 waves/SIMD", k_traffic<false, false, 8>, 100, K, px * 4);
+    }
     run("loads + stores, 8 waves/SIMD", k_traffic<true, true, 8>, 100, 0, px * 4);
     run("loads + stores, 6 waves, 200-row segments", k_traffic<true, true, 6>, 200, 0, px * 4);
     run("loads + stores, 6 waves, 50-row segments", k_traffic<true, true, 6>, 50, 0, px * 4);
