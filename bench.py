@@ -487,10 +487,10 @@ def run_rank(args) -> None:
                     floor_ms = n_valu * (2.0 * cheap + 4.0 * (1.0 - cheap)) / N_SIMDS / (clock * 1e9) * 1e3
                     valu["issue_class"] = {"cheap_class_share": cheap, "floor_ms_cheap2_full4": floor_ms, "frac_of_floor": floor_ms / k_ms,
                                            "note": "floor = every cheap-class instruction at 2 cycles, every other at 4 (frac_of_floor = floor / "
-                                                   "measured kernel time).  Mixed streams do not reach it: with 25-75 % of full-rate-class "
-                                                   "instructions, in runs of 1 to 48, the micro-benchmark pays 3.6-4.1 cycles for EVERY "
-                                                   "instruction (profiles/r03_issue_rate_ubench.log); cycles_per_valu_inst above is this "
-                                                   "kernel's figure"}
+                                                   "measured kernel time).  A mixed stream does not reach it (profiles/r03_issue_rate_ubench.log: "
+                                                   "3.6-4.1 cycles per instruction for every cheap / full-rate mix in runs of 1 to 48), and three "
+                                                   "bit-identical builds of this kernel with 422-462 M instructions and 20-44 % cheap share run "
+                                                   "within 1 % of each other (DESIGN.md 3.1); without any HBM traffic the kernel keeps 96 % of its time"}
                 roof["valu"] = valu
         out = {
             "metric": cfg["metric"], "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -106,3 +106,24 @@ def test_streamed_leg_and_numa_placement_of_two_ranks(tmp_path):
     q = run_bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "c4", "--streamed", "--no-numa",
                   env_extra={"BENCH_SYSFS_ROOT": str(tmp_path)})
     assert q.returncode == 0 and json.loads(q.stdout.strip().splitlines()[-1])["numa"]["pinned"] is False
+
+
+def test_offline_counters_are_quoted_only_for_the_running_build(monkeypatch):
+    """bench.py quotes HBM traffic / VALU counts from profiles/r0x_pmc_summary.json only when that file was collected on the
+    library (or the sources) this process runs: a matching hash gives the entry, any other build gives None and the reason."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    mine = bench.build_hashes()
+    assert mine["src_sha16"] and len(mine["src_sha16"]) == 16
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+    pmc, src = bench.offline_counters("c2")
+    if summary["c2"]["lib_sha16"] == mine["lib_sha16"] or summary["c2"]["src_sha16"] == mine["src_sha16"]:
+        assert pmc and pmc["hbm_bytes_per_launch"] > 2.3e9 and src.endswith("r03_pmc_summary.json")
+    else:
+        assert pmc is None and "another kernel build" in src
+    monkeypatch.setattr(bench, "build_hashes", lambda: {"lib_sha16": "0" * 16, "src_sha16": "1" * 16})
+    pmc, why = bench.offline_counters("c2")
+    assert pmc is None and "another kernel build" in why and "not quoted" in why
+    pmc, why = bench.offline_counters("no-such-config")
+    assert pmc is None and "does not cover" in why
