@@ -287,6 +287,8 @@ def run_rank(args) -> None:
     from image_processing_amd.synth import synth_bayer_rggb, synth_frame
 
     cfg = config_table()[args.config]
+    if args.batch:  # experiments only: the configurations' own batch sizes are the ones profiles/ and DESIGN.md quote
+        cfg = dict(cfg, batch=args.batch, workload=cfg["workload"] + f" [--batch {args.batch} overrides the batch size]")
     W, H, enc, pool_n, uniq = cfg["w"], cfg["h"], cfg["enc"], cfg["batch"], cfg["uniq"]
     cn = 1 if enc == L.ENC_BAYER_RGGB8 else 3
     nr = len(cfg["ranges"])
@@ -347,6 +349,8 @@ def run_rank(args) -> None:
     for i in range(pool_n):
         frames[i] = torch.roll(base[i % uniq], (2 if cn == 1 else 1) * (i // uniq), dims=0)  # even shifts keep the mosaic phase
     masks = torch.empty((pool_n, nr, H, W), dtype=torch.uint8, device=dev)
+    # with ticket 1 on a stream of its own the two batches in flight write at the same time: one mask buffer each
+    masks_b = torch.empty_like(masks)
     torch.cuda.synchronize()
     frame_bytes, row_bytes = H * W * cn, W * cn
 
@@ -362,7 +366,7 @@ def run_rank(args) -> None:
 
     def enqueue(k):
         off, n, _ = batches[k % len(batches)]
-        g.batch_enqueue(k & 1, frames.data_ptr() + off * frame_bytes, frame_bytes, row_bytes, W, H, n, masks.data_ptr())
+        g.batch_enqueue(k & 1, frames.data_ptr() + off * frame_bytes, frame_bytes, row_bytes, W, H, n, (masks_b if k & 1 else masks).data_ptr())
 
     def wait(k):
         return g.batch_wait(k & 1, raw=raws[k & 1])
@@ -385,13 +389,15 @@ def run_rank(args) -> None:
         enqueue(k)
         wait(k)
     fence()
-    kernel_ms, kernel_frames = [], []
+    kernel_ms, kernel_frames, kernel_spans = [], [], []
+    g.set_profiling(True)  # time zero of the kernel spans: float milliseconds keep their resolution over a short region
     local = np.zeros((n_local, nr, 3), np.int64)
     total = args.steps * nb
 
     def collect(k):
         res = wait(k)
-        kernel_ms.append(g.last_kernel_ms())  # HIP events recorded on the library's stream around the chain kernel(s)
+        kernel_ms.append(g.last_kernel_ms())  # HIP events recorded on the batch's stream around its chain kernel(s)
+        kernel_spans.append(g.last_kernel_span())  # the same two events on the device clock
         off, n, first = batches[k % nb]
         kernel_frames.append(n)
         if k >= total - nb:  # the last step's results, by stream frame id
@@ -437,7 +443,7 @@ def run_rank(args) -> None:
         morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in pipe["morph"]]
         exp = Oracle(fast=True).chain(f, encoding=enc, pre_blur_k=pipe.get("pre_blur_k", 0), post_blur_k=pipe.get("post_blur_k", 0),
                                       morph=morph, ranges=cfg["ranges"], stages=False)
-        got = masks[i].cpu().numpy()
+        got = (masks_b if (total - 1) & 1 else masks)[i].cpu().numpy()
         for r in range(nr):
             assert (got[r] == exp["mask"][r]).all(), f"bench mask of range {r} != oracle"
             idx = batches[-1][2] - a + i
@@ -450,12 +456,26 @@ def run_rank(args) -> None:
         k_ms = ms_sum / len(kernel_ms)  # per batch launch (one chain kernel on the fused path)
         launches = kernel_ms[-1][1]
         bytes_per_launch = algo_bytes * (sum(kernel_frames) / len(kernel_frames))
-        achieved = algo_bytes * sum(kernel_frames) / (ms_sum * 1e-3) / 1e9
+        # The two tickets run on two streams, so the kernels of consecutive batches overlap on the GPU: the time the chain
+        # kernels took is the UNION of their spans, not the sum of their lengths (equal when nothing overlaps).
+        busy_ms, end = 0.0, -1.0
+        for t0_, t1_ in sorted(kernel_spans):
+            if t1_ > end:
+                busy_ms += t1_ - max(t0_, end)
+                end = t1_
+        in_flight = ms_sum / busy_ms
+        k_eff = busy_ms / len(kernel_spans)  # kernel time per batch while the chain kernels run
+        achieved = algo_bytes * sum(kernel_frames) / (busy_ms * 1e-3) / 1e9
         fused = plan.startswith("fused chain kernel")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None, "traffic_source": None,
                 "kernel": kernel_name(cfg, plan), "kernel_ms_per_launch": k_ms if fused else None,
                 "kernel_ms_per_batch": k_ms, "launches_per_batch": launches,
+                "batches_in_flight": in_flight, "kernel_ms_per_batch_effective": k_eff,
+                "timing": "HIP events around each batch's kernels on the batch's own stream (kernel_ms_per_batch = average span, what "
+                          "rocprofv3 --kernel-trace --stats reports per launch); consecutive batches run on two streams and overlap on "
+                          "the GPU, so achieved = algorithmic bytes of all batches / union of the spans "
+                          "(kernel_ms_per_batch_effective = union / batches = kernel_ms_per_batch / batches_in_flight)",
                 "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_px": cfg["bpp"]}
         pmc, src = offline_counters(args.config if not args.unfused else "none")
         if pmc is None:
@@ -471,7 +491,7 @@ def run_rank(args) -> None:
                                       f"{pmc['matched_on']} {pmc.get(pmc['matched_on'])})")
             if pmc.get("valu_insts_per_launch"):
                 n_valu = pmc["valu_insts_per_launch"]
-                lane_ops = n_valu * 64 / (k_ms * 1e-3)
+                lane_ops = n_valu * 64 / (k_eff * 1e-3)
                 clock = pmc.get("clock_ghz") or 2.4
                 valu = {"achieved_lane_ops_per_s": lane_ops, "peak": VALU_PEAK_LANE_OPS, "frac": lane_ops / VALU_PEAK_LANE_OPS,
                         "peak_note": "machine peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz (one wave64 instruction per 2 cycles); "
@@ -479,13 +499,13 @@ def run_rank(args) -> None:
                         "valu_insts_per_launch": n_valu,
                         "lane_ops_per_px": n_valu * 64 / (bytes_per_launch / cfg["bpp"]),
                         "clock_ghz": clock, "clock_source": "GRBM_GUI_ACTIVE / 8 / kernel time (offline pass)" if pmc.get("clock_ghz") else "assumed",
-                        "cycles_per_valu_inst": k_ms * 1e-3 * clock * 1e9 * N_SIMDS / n_valu,
+                        "cycles_per_valu_inst": k_eff * 1e-3 * clock * 1e9 * N_SIMDS / n_valu,
                         "insts_source": roof["traffic_source"]}
                 cheap = pmc.get("cheap_class_share")  # static share of cheap-class instructions in the main loop (ISA count)
                 if cheap is not None:
                     # issue-class floor: every cheap-class instruction at 2 cycles, every other at 4, nothing else in the way
                     floor_ms = n_valu * (2.0 * cheap + 4.0 * (1.0 - cheap)) / N_SIMDS / (clock * 1e9) * 1e3
-                    valu["issue_class"] = {"cheap_class_share": cheap, "floor_ms_cheap2_full4": floor_ms, "frac_of_floor": floor_ms / k_ms,
+                    valu["issue_class"] = {"cheap_class_share": cheap, "floor_ms_cheap2_full4": floor_ms, "frac_of_floor": floor_ms / k_eff,
                                            "note": "floor = every cheap-class instruction at 2 cycles, every other at 4 (frac_of_floor = floor / "
                                                    "measured kernel time).  A mixed stream does not reach it (profiles/r03_issue_rate_ubench.log: "
                                                    "3.6-4.1 cycles per instruction for every cheap / full-rate mix in runs of 1 to 48), and three "
@@ -653,6 +673,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5", "pp", "pe"], default="c2")
+    ap.add_argument("--batch", type=int, default=0, help="override the configuration's frames per batch (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true", help="c3: skip the streamed (PCIe) leg")
     ap.add_argument("--unfused", action="store_true", help="time the stage-by-stage path instead")

@@ -90,6 +90,7 @@ _SIGS = {
     "imgproc_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "imgproc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "imgproc_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "imgproc_last_kernel_span": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "imgproc_pipeline_is_fused": (C.c_int, [C.c_void_p]),
     "imgproc_pipeline_plan": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "imgproc_synchronize": (C.c_int, [C.c_void_p]),

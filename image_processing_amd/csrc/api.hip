@@ -216,8 +216,11 @@ struct imgproc_ctx {
         int n = 0, nr = 0, launches = 0, second = 0;
     } batch[2];
     int last_ticket = -1;  // the batch imgproc_last_kernel_ms reports on
-    u8 *d_thresh_batch = nullptr;  // inRange planes of a device batch for the front + bit-plane path (grown on demand)
-    size_t thresh_batch_bytes = 0;
+    // inRange planes of a device batch for the front + bit-plane path (grown on demand), one buffer per ticket
+    u8 *d_thresh_batch[2] = {nullptr, nullptr};
+    size_t thresh_batch_bytes[2] = {0, 0};
+    hipStream_t stream2 = nullptr;  // ticket 1 of the one- and two-launch batch paths runs here (IMGPROC_BATCH_STREAMS=1: off)
+    hipEvent_t ev_ref = nullptr;    // time zero of imgproc_last_kernel_span (re-recorded by imgproc_set_profiling)
     unsigned char *na_scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress at create)
     unsigned long long *h_na_mom = nullptr;  // pinned landing buffer of the no-allocation entry point (max_batch frames)
     u8 *d_s0 = nullptr, *d_s1 = nullptr;  // scratch for single-stage calls (max frame, 3 ch)
@@ -593,6 +596,11 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
     auto build = [&]() -> int {
         HIPCHK(c, hipSetDevice(c->cfg.device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // ticket 1 of the device-batch path gets a stream of its own unless IMGPROC_BATCH_STREAMS=1 (A/B: DESIGN.md 4)
+        const char *bs = getenv("IMGPROC_BATCH_STREAMS");
+        if (!bs || atoi(bs) != 1) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreate(&c->ev_ref));
+        HIPCHK(c, hipEventRecord(c->ev_ref, c->stream));
         // HSV reciprocal tables: cvRound == round-half-even == lrint
         int tab[512];
         tab[0] = tab[256] = 0;
@@ -660,6 +668,7 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto &s : c->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         free_slot(s);
@@ -667,7 +676,8 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     free_slot(c->work);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_groups) (void)hipFree(c->d_groups);
-    if (c->d_thresh_batch) (void)hipFree(c->d_thresh_batch);
+    for (u8 *b : c->d_thresh_batch)
+        if (b) (void)hipFree(b);
     if (c->d_s0) (void)hipFree(c->d_s0);
     if (c->d_s1) (void)hipFree(c->d_s1);
     if (c->d_s_mom) (void)hipFree(c->d_s_mom);
@@ -680,6 +690,8 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
         if (b.ev_done) (void)hipEventDestroy(b.ev_done);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_ref) (void)hipEventDestroy(c->ev_ref);
     delete c->copy_pool;
     delete c;
 }
@@ -1040,28 +1052,42 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
         return IMGPROC_OK;
     }
     Slot &s = c->work;  // stage-by-stage planes of the batch path; all its users run on c->stream, in order
-    HIPCHK(c, hipMemsetAsync(bt.d_mom, 0, mom_bytes, c->stream));
-    if (c->profiling) HIPCHK(c, hipEventRecord(bt.ev_k0, c->stream));
-    if (p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks)) {
+    const bool one_launch = p.fused_ok && ipf::can_launch_fused(p.fused, d_frames, frame_stride, row_stride, w, h, d_masks);
+    const bool two_launch = !one_launch && p.front_ok && p.bm_ok &&
+                            ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks);
+    // frames that need no demosaic / pre-blur go through the fused HSV + Gaussian + inRange kernel a whole group at a time
+    const bool group_fused = !one_launch && !two_launch && bit_plane_tail(p) && gauss_fused_wanted(p) &&
+                             p.pipe.encoding != IMGPROC_ENC_BAYER_RGGB8 && p.pipe.pre_blur_k <= 1 &&
+                             ipk::gauss_fused_ok((const u8 *)d_frames, frame_stride, row_stride, w, h, p.post, p.bounds);
+    // Paths that touch nothing of the context but read-only tables and this ticket's own buffers may run ticket 1 on a
+    // stream of its own (default; IMGPROC_BATCH_STREAMS=1 turns it off), so kernels of consecutive batches overlap on the GPU.
+    hipStream_t const st = (c->stream2 && ticket == 1 && (one_launch || two_launch || group_fused)) ? c->stream2 : c->stream;
+    u8 *&planes = c->d_thresh_batch[ticket];
+    size_t &planes_bytes = c->thresh_batch_bytes[ticket];
+    auto grow_planes = [&](size_t need) -> int {  // grown on demand, kept for the life of the context; only this ticket uses it
+        if (need <= planes_bytes) return IMGPROC_OK;
+        if (planes) HIPCHK(c, hipFree(planes));  // the ticket is not pending: nothing in flight reads it
+        planes = nullptr;
+        planes_bytes = 0;
+        HIPCHK(c, hipMalloc((void **)&planes, need));
+        planes_bytes = need;
+        return IMGPROC_OK;
+    };
+    HIPCHK(c, hipMemsetAsync(bt.d_mom, 0, mom_bytes, st));
+    if (c->profiling) HIPCHK(c, hipEventRecord(bt.ev_k0, st));
+    if (one_launch) {
         HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks, bt.d_mom,
-                                    c->d_tables, c->stream));
+                                    c->d_tables, st));
         bt.launches = 1;
-    } else if (p.front_ok && p.bm_ok && ipf::can_launch_fused(p.front, d_frames, frame_stride, row_stride, w, h, d_masks)) {
+    } else if (two_launch) {
         const bool as_bits = ipf::front_writes_bits(w);
-        const size_t need = as_bits ? (size_t)n * nr * h * ipm::bit_words(w) * 4 : (size_t)n * nr * px;
-        if (need > c->thresh_batch_bytes) {  // grown on demand, kept for the life of the context
-            HIPCHK(c, hipStreamSynchronize(c->stream));  // the other ticket may still be using the old buffer
-            if (c->d_thresh_batch) HIPCHK(c, hipFree(c->d_thresh_batch));
-            c->d_thresh_batch = nullptr;
-            c->thresh_batch_bytes = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_thresh_batch, need));
-            c->thresh_batch_bytes = need;
-        }
-        uint32_t *bits = as_bits ? reinterpret_cast<uint32_t *>(c->d_thresh_batch) : nullptr;
-        HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, c->d_thresh_batch,
-                                    nullptr, c->d_tables, c->stream, bits));
-        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, c->d_thresh_batch, (u8 *)d_masks, bt.d_mom, w, h, n * nr,
-                                       p.pipe.second_order, c->stream, bits));
+        rc = grow_planes(as_bits ? (size_t)n * nr * h * ipm::bit_words(w) * 4 : (size_t)n * nr * px);
+        if (rc) return rc;
+        uint32_t *bits = as_bits ? reinterpret_cast<uint32_t *>(planes) : nullptr;
+        HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, planes,
+                                    nullptr, c->d_tables, st, bits));
+        HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, planes, (u8 *)d_masks, bt.d_mom, w, h, n * nr,
+                                       p.pipe.second_order, st, bits));
         bt.launches = 2;
     } else if (bit_plane_tail(p)) {
         // stage kernels per frame up to the inRange bit planes, then the bit-plane morphology of a whole group of frames in
@@ -1069,19 +1095,9 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
         const size_t per_frame = (size_t)nr * h * ipm::bit_words(w) * 4;
         const size_t cap = (size_t)1 << 30;  // at most 1 GiB of bit planes at a time
         const int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap / std::max<size_t>(per_frame, 1)));
-        const size_t need = per_frame * group;
-        if (need > c->thresh_batch_bytes) {  // grown on demand, kept for the life of the context
-            HIPCHK(c, hipStreamSynchronize(c->stream));  // the other ticket may still be using the old buffer
-            if (c->d_thresh_batch) HIPCHK(c, hipFree(c->d_thresh_batch));
-            c->d_thresh_batch = nullptr;
-            c->thresh_batch_bytes = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_thresh_batch, need));
-            c->thresh_batch_bytes = need;
-        }
-        uint32_t *bits = reinterpret_cast<uint32_t *>(c->d_thresh_batch);
-        // frames that need no demosaic / pre-blur go through the fused HSV + Gaussian + inRange kernel a whole group at a time
-        const bool group_fused = gauss_fused_wanted(p) && p.pipe.encoding != IMGPROC_ENC_BAYER_RGGB8 && p.pipe.pre_blur_k <= 1 &&
-                                 ipk::gauss_fused_ok((const u8 *)d_frames, frame_stride, row_stride, w, h, p.post, p.bounds);
+        rc = grow_planes(per_frame * group);
+        if (rc) return rc;
+        uint32_t *bits = reinterpret_cast<uint32_t *>(planes);
         if (!group_fused) {  // the stage kernels work in the context's own planes
             rc = ensure_work(c);
             if (rc) return rc;
@@ -1090,17 +1106,17 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
             const int gn = std::min(group, n - g0);
             if (group_fused) {
                 HIPCHK(c, ipk::launch_gauss_fused((const u8 *)d_frames + (size_t)g0 * frame_stride, frame_stride, row_stride, bits, w, h, gn,
-                                                  p.post, p.bounds, p.pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0, c->d_tables, c->stream));
+                                                  p.post, p.bounds, p.pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0, c->d_tables, st));
                 bt.launches++;
             }
             for (int i = 0; i < gn && !group_fused; i++) {
                 rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)(g0 + i) * frame_stride, row_stride, w, h, nullptr, nullptr,
-                                 &bt.launches, c->stream, IMGPROC_STAGE_MASK, bits + (size_t)i * (per_frame / 4));
+                                 &bt.launches, st, IMGPROC_STAGE_MASK, bits + (size_t)i * (per_frame / 4));
                 if (rc) return rc;
             }
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)g0 * nr * px : nullptr;  // no mask buffer: moments only
             HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, nullptr, mout, bt.d_mom + (size_t)g0 * nr * 6, w, h, gn * nr,
-                                           p.pipe.second_order, c->stream, bits));
+                                           p.pipe.second_order, st, bits));
             bt.launches++;
         }
     } else {
@@ -1109,16 +1125,16 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
         for (int i = 0; i < n; i++) {
             u8 *mout = d_masks ? (u8 *)d_masks + (size_t)i * nr * px : s.d_mask;
             rc = run_unfused(c, s, (const u8 *)d_frames + (size_t)i * frame_stride, row_stride, w, h, mout,
-                             bt.d_mom + (size_t)i * nr * 6, &bt.launches, c->stream);
+                             bt.d_mom + (size_t)i * nr * 6, &bt.launches, st);
             if (rc) return rc;
         }
     }
     if (c->profiling) {
-        HIPCHK(c, hipEventRecord(bt.ev_k1, c->stream));
+        HIPCHK(c, hipEventRecord(bt.ev_k1, st));
         bt.timed = true;
     }
-    HIPCHK(c, hipMemcpyAsync(bt.h_mom, bt.d_mom, mom_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(bt.ev_done, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bt.h_mom, bt.d_mom, mom_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(bt.ev_done, st));
     bt.pending = true;
     return IMGPROC_OK;
 }
@@ -1443,6 +1459,11 @@ IMGPROC_API int imgproc_set_profiling(imgproc_ctx *c, int on)
     if (!c) return IMGPROC_EINVAL;
     c->profiling = on != 0;
     c->last_ticket = -1;
+    if (on) {  // time zero of imgproc_last_kernel_span
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        HIPCHK(c, hipEventRecord(c->ev_ref, c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev_ref));
+    }
     return IMGPROC_OK;
 }
 IMGPROC_API int imgproc_last_kernel_ms(imgproc_ctx *c, float *ms, int *launches)
@@ -1456,11 +1477,23 @@ IMGPROC_API int imgproc_last_kernel_ms(imgproc_ctx *c, float *ms, int *launches)
     if (launches) *launches = bt.launches;
     return IMGPROC_OK;
 }
+IMGPROC_API int imgproc_last_kernel_span(imgproc_ctx *c, float *t0_ms, float *t1_ms)
+{
+    if (!c || !t0_ms || !t1_ms) return IMGPROC_EINVAL;
+    if (c->last_ticket < 0 || !c->batch[c->last_ticket].timed) return fail(c, IMGPROC_ESTATE, "no profiled batch call yet");
+    const imgproc_ctx::Batch &bt = c->batch[c->last_ticket];
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(bt.ev_k1));
+    HIPCHK(c, hipEventElapsedTime(t0_ms, c->ev_ref, bt.ev_k0));
+    HIPCHK(c, hipEventElapsedTime(t1_ms, c->ev_ref, bt.ev_k1));
+    return IMGPROC_OK;
+}
 IMGPROC_API int imgproc_synchronize(imgproc_ctx *c)
 {
     if (!c) return IMGPROC_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     for (auto &s : c->slots) HIPCHK(c, hipStreamSynchronize(s.stream));
     return IMGPROC_OK;
 }

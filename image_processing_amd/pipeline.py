@@ -266,6 +266,12 @@ class ImgProc:
         self._chk(self.lib.imgproc_last_kernel_ms(self._ctx, C.byref(ms), C.byref(n)), "imgproc_last_kernel_ms")
         return ms.value, n.value
 
+    def last_kernel_span(self):
+        """(start, end) of the last waited batch's kernels in ms on the device clock since set_profiling(True)."""
+        t0, t1 = C.c_float(), C.c_float()
+        self._chk(self.lib.imgproc_last_kernel_span(self._ctx, C.byref(t0), C.byref(t1)), "imgproc_last_kernel_span")
+        return t0.value, t1.value
+
     def synchronize(self):
         self._chk(self.lib.imgproc_synchronize(self._ctx), "imgproc_synchronize")
 

@@ -158,9 +158,13 @@ int imgproc_process_batch(imgproc_ctx *ctx, const uint8_t *frames, size_t frame_
 int imgproc_process_batch_device(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride, size_t row_stride,
                                  int w, int h, int n, void *d_masks, imgproc_result *out);
 /* The same in two halves, so that two device batches can be in flight (offline bag processing, the benchmark):
- * enqueue puts batch `ticket` (0 or 1) on the context's stream and returns; wait blocks until it is done and fills
- * out[n] (out may be NULL).  d_frames / d_masks must stay valid until the wait.  process_batch_device is
- * enqueue(ticket 0) + wait(0).  Like it, these have no call site in the reference (its nodes see one frame at a time). */
+ * enqueue puts batch `ticket` (0 or 1) on a stream of the context and returns; wait blocks until it is done and fills
+ * out[n] (out may be NULL).  d_frames / d_masks must stay valid until the wait.  The two tickets are independent of
+ * each other: pipelines that run as one or two launches per batch put ticket 1 on a stream of its own, so its kernels
+ * overlap ticket 0's on the GPU (3-16 % more frames/s than one stream; IMGPROC_BATCH_STREAMS=1 in the
+ * environment at imgproc_create keeps both on one stream) -- the d_masks of two batches in flight must therefore not
+ * overlap, and neither batch may read what the other writes.  process_batch_device is enqueue(ticket 0) + wait(0).
+ * Like it, these have no call site in the reference (its nodes see one frame at a time). */
 int imgproc_batch_enqueue(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
                           int n, void *d_masks, int ticket);
 int imgproc_batch_wait(imgproc_ctx *ctx, int ticket, imgproc_result *out);
@@ -221,6 +225,10 @@ int imgproc_dev_download(imgproc_ctx *ctx, void *dst, const void *dptr, size_t b
  * that was waited for last, and how many launches that was. */
 int imgproc_set_profiling(imgproc_ctx *ctx, int on);
 int imgproc_last_kernel_ms(imgproc_ctx *ctx, float *ms, int *launches);
+/* The same two events as times on the device clock, in ms since the last imgproc_set_profiling(ctx, 1): with two
+ * batches in flight on two streams the spans of consecutive batches overlap, and a caller that wants the rate of the
+ * kernels while they run needs the union of the spans, not the sum of their lengths (bench.py: roofline). */
+int imgproc_last_kernel_span(imgproc_ctx *ctx, float *t0_ms, float *t1_ms);
 /* 1 if the current pipeline runs as one fused kernel, 0 if stage-by-stage */
 int imgproc_pipeline_is_fused(const imgproc_ctx *ctx);
 /* human-readable description of how the current pipeline will run (which kernels), for logs and tests */

@@ -459,6 +459,56 @@ def test_two_batches_in_flight(gpu, oracle):
             gpu.dev_free(p)
 
 
+@pytest.mark.parametrize("preset", ["baseline", "polygon_path", "stress", "bayer_baseline"])
+def test_two_tickets_overlap_on_two_streams(gpu, oracle, preset):
+    """Ticket 1 runs on a stream of its own (include/imgproc.h, imgproc_batch_enqueue), with its own inRange planes on the
+    two-launch paths: two DIFFERENT batches in flight, several rounds, each equal to its one-call result and to the oracle;
+    the kernel spans of the two tickets are reported on one clock."""
+    h, w, n = 150, 520, 3
+    bayer = preset == "bayer_baseline"
+    kw = dict(pre_blur_k=0, post_blur_k=15, morph=[ip.E(9, L.ELLIPSE), ip.D(9, L.ELLIPSE)]) if preset == "stress" else PRESETS[preset.replace("bayer_", "")]
+    ranges = [((20 * r, 40, 40), (20 * r + 50, 255, 255)) for r in range(8)] if preset == "stress" else [DEFAULT_RANGE]
+    nr = len(ranges)
+    if bayer:
+        fa, fb = (np.stack([synth_bayer_rggb(w, h, i, seed=s) for i in range(n)]) for s in (21, 22))
+    else:
+        fa, fb = synth_batch(w, h, n, seed=21), synth_batch(w, h, n, seed=22)
+    gpu.set_pipeline(encoding=L.ENC_BAYER_RGGB8 if bayer else L.ENC_BGR8, **kw)
+    gpu.set_ranges(ranges)
+    cn = 1 if bayer else 3
+    d_a, d_b = gpu.dev_alloc(fa.nbytes), gpu.dev_alloc(fb.nbytes)
+    d_ma, d_mb = gpu.dev_alloc(n * nr * w * h), gpu.dev_alloc(n * nr * w * h)
+    try:
+        gpu.dev_upload(d_a, fa)
+        gpu.dev_upload(d_b, fb)
+        ref_a = gpu.process_batch_device(d_a, w * h * cn, w * cn, w, h, n, d_ma)
+        mask_a = gpu.dev_download(d_ma, (n, nr, h, w)).copy()
+        ref_b = gpu.process_batch_device(d_b, w * h * cn, w * cn, w, h, n, d_ma)
+        mask_b = gpu.dev_download(d_ma, (n, nr, h, w)).copy()
+        assert ref_a != ref_b
+        gpu.set_profiling(True)
+        spans = []
+        gpu.batch_enqueue(0, d_a, w * h * cn, w * cn, w, h, n, d_ma)
+        for k in range(1, 8):  # ticket k & 1 takes batch A on even k, B on odd k; batch k - 1 is collected after k is enqueued
+            gpu.batch_enqueue(k & 1, d_b if k & 1 else d_a, w * h * cn, w * cn, w, h, n, d_mb if k & 1 else d_ma)
+            assert gpu.batch_wait((k - 1) & 1, n=n) == (ref_b if (k - 1) & 1 else ref_a)
+            spans.append(gpu.last_kernel_span())
+        assert gpu.batch_wait(1, n=n) == ref_b
+        spans.append(gpu.last_kernel_span())
+        gpu.set_profiling(False)
+        assert (gpu.dev_download(d_ma, (n, nr, h, w)) == mask_a).all()
+        assert (gpu.dev_download(d_mb, (n, nr, h, w)) == mask_b).all()
+        assert all(0 <= t0 < t1 for t0, t1 in spans) and all(b[1] > a[1] for a, b in zip(spans, spans[2:]))  # same ticket: in order
+        exp = oracle.chain(fb[1], encoding=L.ENC_BAYER_RGGB8 if bayer else L.ENC_BGR8, morph=morph_tuples(kw["morph"]), ranges=ranges,
+                           stages=False, **{k: v for k, v in kw.items() if k != "morph"})
+        for r in range(nr):
+            assert (mask_b[1, r] == exp["mask"][r]).all()
+            check_moments(ref_b[1][r], exp["moments"][r])
+    finally:
+        for p in (d_a, d_b, d_ma, d_mb):
+            gpu.dev_free(p)
+
+
 @pytest.mark.parametrize("w", [32, 33, 37, 101, 249, 250, 251, 255, 257, 499, 501, 997])
 @pytest.mark.parametrize("preset", ["pose_estimate", "baseline", "polygon_path"])
 def test_odd_widths_stay_on_the_fast_path(gpu, oracle, w, preset):
