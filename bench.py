@@ -59,11 +59,11 @@ def config_table():
 
     bands = [(20 * i, 20 * i + 19) for i in range(8)]
     return {
-        "c1": dict(w=640, h=480, enc=L.ENC_BGR8, batch=64, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+        "c1": dict(w=640, h=480, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
                    pipe=dict(morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE], cpu_budget_s=20.0,
                    metric="frames/sec at 640x480 BGR8, HSV inRange + 3x3 erode + 3x3 dilate + centroid (no blur)",
                    workload="configs[0] (the reference's CPU-runnable case, pose_estimate.cpp:203-206,405-415 with one erode and one "
-                            "dilate): 640x480 BGR8, batches of 64 frames, BGR2HSV + inRange + erode3 + dilate3 + moments; the CPU leg "
+                            "dilate): 640x480 BGR8, batches of 256 frames, BGR2HSV + inRange + erode3 + dilate3 + moments; the CPU leg "
                             "(`cpu_baseline`) is this configuration's subject, `value` is the GPU leg (device-resident) beside it"),
         "c2": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
                    pipe=dict(post_blur_k=5, morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE],

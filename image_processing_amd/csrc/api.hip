@@ -1062,6 +1062,7 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
     // Paths that touch nothing of the context but read-only tables and this ticket's own buffers may run ticket 1 on a
     // stream of its own (default; IMGPROC_BATCH_STREAMS=1 turns it off), so kernels of consecutive batches overlap on the GPU.
     hipStream_t const st = (c->stream2 && ticket == 1 && (one_launch || two_launch || group_fused)) ? c->stream2 : c->stream;
+    const bool overlapped = c->stream2 && c->batch[ticket ^ 1].pending;  // the other ticket's kernels run beside this batch's
     u8 *&planes = c->d_thresh_batch[ticket];
     size_t &planes_bytes = c->thresh_batch_bytes[ticket];
     auto grow_planes = [&](size_t need) -> int {  // grown on demand, kept for the life of the context; only this ticket uses it
@@ -1077,7 +1078,7 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
     if (c->profiling) HIPCHK(c, hipEventRecord(bt.ev_k0, st));
     if (one_launch) {
         HIPCHK(c, ipf::launch_fused(p.fused, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, (u8 *)d_masks, bt.d_mom,
-                                    c->d_tables, st));
+                                    c->d_tables, st, nullptr, overlapped));
         bt.launches = 1;
     } else if (two_launch) {
         const bool as_bits = ipf::front_writes_bits(w);
@@ -1085,7 +1086,7 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
         if (rc) return rc;
         uint32_t *bits = as_bits ? reinterpret_cast<uint32_t *>(planes) : nullptr;
         HIPCHK(c, ipf::launch_fused(p.front, (const u8 *)d_frames, frame_stride, row_stride, w, h, n, planes,
-                                    nullptr, c->d_tables, st, bits));
+                                    nullptr, c->d_tables, st, bits, overlapped));
         HIPCHK(c, ipm::launch_bitmorph(p.bm, c->d_groups, planes, (u8 *)d_masks, bt.d_mom, w, h, n * nr,
                                        p.pipe.second_order, st, bits));
         bt.launches = 2;

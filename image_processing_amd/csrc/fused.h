@@ -33,9 +33,11 @@ bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_
 
 // frames: n frames at d_frames + i*frame_stride; masks (may be null): [n][n_ranges][h][w]; moments added into
 // d_mom[n][n_ranges][6] (caller zeroes)
+// overlapped: another launch of the context is in flight on the other batch stream (imgproc_batch_enqueue), so the end of
+// this launch is covered by that one and segments can be tall (fewer look-ahead rows); alone, ~100-row segments win.
 hipError_t launch_fused(const FusedPlan &plan, const ipk::u8 *d_frames, size_t frame_stride, size_t row_stride, int w,
                         int h, int n, ipk::u8 *d_masks, unsigned long long *d_mom, const int *d_tables,
-                        hipStream_t stream, uint32_t *d_bits = nullptr);
+                        hipStream_t stream, uint32_t *d_bits = nullptr, bool overlapped = false);
 // A front plan (plan_front) can hand its inRange result to the bit-plane back end as bits instead of bytes when the
 // strips' borders fall on byte borders of the bitmap: pass d_bits ([n][n_ranges][h][(w+31)/32] words) instead of d_masks.
 inline bool front_writes_bits(int w) { return (w & 3) == 0; }

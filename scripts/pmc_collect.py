@@ -27,12 +27,30 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recurs
     for r in csv.DictReader(open(f)):
         if ours(r["Name"]):
             kern[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])}
+# The two tickets of a device batch run on two streams, so launches overlap in the kernel trace: the sum of the launch
+# durations over the union of their spans is the number of launches in flight while the chain kernels run.
+spans = []
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if ours(r["Kernel_Name"]):
+            spans.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+trace = None
+if spans:
+    union, end = 0, -1
+    for t0, t1 in sorted(spans):
+        if t1 > end:
+            union += t1 - max(t0, end)
+            end = t1
+    total = sum(t1 - t0 for t0, t1 in spans)
+    trace = {"launches": len(spans), "sum_ns": total, "union_ns": union, "launches_in_flight": total / union}
 for pas in ("fetch", "write", "grbm", "sq1", "sq2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(out, pas, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if ours(r["Kernel_Name"]):
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if pas == "grbm":  # counter passes run one dispatch at a time: the duration of the launch on its own, same dispatch as the cycles
+                    acc[short(r["Kernel_Name"])]["serial_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for k, cs in acc.items():
         d = kern.setdefault(k, {})
         for c, v in cs.items():
@@ -48,4 +66,4 @@ sys.path.insert(0, ROOT)
 from bench import build_hashes  # the same two hashes bench.py compares at run time
 
 assert build_hashes()["lib_sha16"] == sha
-print(json.dumps({"config": cfg, "lib_sha16": sha, "src_sha16": build_hashes()["src_sha16"], "bench_line_under_rocprof": bench, "kernels": kern}, indent=1))
+print(json.dumps({"config": cfg, "lib_sha16": sha, "src_sha16": build_hashes()["src_sha16"], "bench_line_under_rocprof": bench, "kernel_trace": trace, "kernels": kern}, indent=1))

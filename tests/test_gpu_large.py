@@ -209,3 +209,41 @@ def test_submit_pinned_skips_the_staging_copy(oracle, padded, preset):
                        stages=False)
     assert (got[4][1] == exp["mask"][0]).all()
     assert [got[4][0][0][k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")] == [int(v) for v in exp["moments"][0]]
+
+
+@pytest.mark.parametrize("preset", ["baseline", "polygon_path"])
+def test_overlapped_batches_take_tall_segments(oracle, preset):
+    """With the other ticket in flight a large batch is cut into ~300-row segments instead of ~100-row ones
+    (fused.hip, launch_fused `overlapped`): 96 frames of 1920x1200 structured noise on ticket 1 while ticket 0 runs, equal
+    to the same batch processed alone (other segment borders) mask for mask, and to the oracle on one frame."""
+    w, h, n, uniq = 1920, 1200, 96, 3
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    blob = (np.sin(xx / 41.0) * np.cos(yy / 23.0)) > 0.1
+    base = [np.where(blob[:, :, None], rng.integers(0, 256, (h, w, 3), dtype=np.uint8), 40).astype(np.uint8) for _ in range(uniq)]
+    frames = np.stack([np.roll(base[i % uniq], 7 * (i // uniq), axis=0) for i in range(n)])
+    kw = dict(baseline=dict(post_blur_k=5, morph=ip.MORPH_BASELINE),
+              polygon_path=dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH))[preset]
+    rg = [((0, 30, 60), (120, 256, 256))]
+    with ip.ImgProc(w, h, n_slots=1, max_batch=n) as g:
+        g.set_pipeline(**kw)
+        g.set_ranges(rg)
+        d_in = g.dev_alloc(frames.nbytes)
+        d_m = [g.dev_alloc(n * w * h) for _ in range(3)]
+        try:
+            g.dev_upload(d_in, frames)
+            alone = g.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, d_m[0])
+            g.batch_enqueue(0, d_in, w * h * 3, w * 3, w, h, n, d_m[1])
+            g.batch_enqueue(1, d_in, w * h * 3, w * 3, w, h, n, d_m[2])  # ticket 0 pending: overlapped
+            assert g.batch_wait(0, n=n) == alone
+            assert g.batch_wait(1, n=n) == alone
+            m_alone = g.dev_download(d_m[0], (n, h, w))
+            m_over = g.dev_download(d_m[2], (n, h, w))
+        finally:
+            g.dev_free(d_in)
+            for p in d_m:
+                g.dev_free(p)
+    assert (m_alone == m_over).all()
+    exp = oracle.chain(frames[50], morph=morph_tuples(kw["morph"]), ranges=rg, stages=False, **{k: v for k, v in kw.items() if k != "morph"})
+    assert (m_over[50] == exp["mask"][0]).all()
+    assert [alone[50][0][k] for k in KEYS] == [int(v) for v in exp["moments"][0][:3]] and alone[50][0]["m00"] > 0
