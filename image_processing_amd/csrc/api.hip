@@ -1107,7 +1107,7 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
             const int gn = std::min(group, n - g0);
             if (group_fused) {
                 HIPCHK(c, ipk::launch_gauss_fused((const u8 *)d_frames + (size_t)g0 * frame_stride, frame_stride, row_stride, bits, w, h, gn,
-                                                  p.post, p.bounds, p.pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0, c->d_tables, st));
+                                                  p.post, p.bounds, p.pipe.encoding == IMGPROC_ENC_RGB8 ? 2 : 0, c->d_tables, st, overlapped));
                 bt.launches++;
             }
             for (int i = 0; i < gn && !group_fused; i++) {

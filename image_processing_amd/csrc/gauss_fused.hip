@@ -325,7 +325,8 @@ bool gauss_fused_ok(const u8 *src, size_t frame_stride, size_t sstride, int w, i
 }
 
 hipError_t launch_gauss_fused(const u8 *src, size_t frame_stride, size_t sstride, uint32_t *bits, int w, int h, int n,
-                              const Taps &taps, const Bounds &b, int bidx, const int *d_hsv_tables, hipStream_t stream)
+                              const Taps &taps, const Bounds &b, int bidx, const int *d_hsv_tables, hipStream_t stream,
+                              bool overlapped)
 {
     if (n <= 0 || w <= 0 || h <= 0) return hipSuccess;
     GfArgs a{};
@@ -338,9 +339,12 @@ hipError_t launch_gauss_fused(const u8 *src, size_t frame_stride, size_t sstride
     // every segment runs two extra blocks (the one above, the one below), yet short segments win: a block's steps are a
     // chain of dependent LDS / MFMA phases at the 3 waves per SIMD the LDS allows, and a finer grain evens out the rounds.
     // Measured at 4 frames of 7680x4320 (960 strip columns): 8 segments per column 0.433 ms, 12 0.397, 16 0.375, 23 0.360,
-    // 34 0.362, 46 0.371, 68 0.416 -> about 24 k waves per launch, at least 4 blocks per segment
+    // 34 0.362, 46 0.371, 68 0.416 -> about 24 k waves per launch, at least 4 blocks per segment.  With another batch's
+    // launches in flight on the other stream (overlapped) the rounds even out by themselves and fewer, taller segments win:
+    // whole step of that configuration at 9 / 13 / 18 / 26 / 34 segments 0.661 / 0.622 / 0.600 / 0.614 / 0.625 ms -> 16 k waves
     const long long cols = (long long)a.nstrips * n;
-    int nsegs = (int)std::max<long long>(1, std::min<long long>((24576 + cols - 1) / cols, (a.nblocks + 3) / 4));
+    const long long waves = overlapped ? 16384 : 24576;
+    int nsegs = (int)std::max<long long>(1, std::min<long long>((waves + cols - 1) / cols, (a.nblocks + 3) / 4));
     if (const char *e = getenv("IMGPROC_GAUSS_SEGS")) nsegs = std::max(1, std::min(atoi(e), a.nblocks));
     a.seg_blocks = (a.nblocks + nsegs - 1) / nsegs;
     a.nsegs = (a.nblocks + a.seg_blocks - 1) / a.seg_blocks;

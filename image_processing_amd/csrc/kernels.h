@@ -49,7 +49,8 @@ hipError_t launch_in_range_bits(const u8 *src, size_t sstride, uint32_t *dst, in
 // RGB (bidx 2) at src + i * frame_stride -> bits[n][b.n][h][(w+31)/32]
 bool gauss_fused_ok(const u8 *src, size_t frame_stride, size_t sstride, int w, int h, const Taps &taps, const Bounds &b);
 hipError_t launch_gauss_fused(const u8 *src, size_t frame_stride, size_t sstride, uint32_t *bits, int w, int h, int n,
-                              const Taps &taps, const Bounds &b, int bidx, const int *d_hsv_tables, hipStream_t stream);
+                              const Taps &taps, const Bounds &b, int bidx, const int *d_hsv_tables, hipStream_t stream,
+                              bool overlapped = false);  // overlapped: another batch's launches run beside this one (fewer, taller segments)
 hipError_t launch_morph(const u8 *src, size_t sstride, u8 *dst, size_t dstride, int w, int h, int kind,
                         const Element &e, hipStream_t stream);
 // adds into d_m[6] (u64: m00 m10 m01 m20 m11 m02); caller zeroes
