@@ -381,13 +381,20 @@ def run_rank(args) -> None:
     # a 23-step run and 0.78 ms from the ~40th step on).  The metric is steady-state throughput, so the device is kept
     # busy with the same work for PREROLL_S before the W warmup steps; nothing of it is timed or reported.
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < PREROLL_S:
-        enqueue(0)
-        wait(0)
+    enqueue(0)
+    k_pre = 1
+    while time.perf_counter() - t_pre < PREROLL_S:  # the same two-in-flight pattern as the timed loop
+        enqueue(k_pre)
+        wait(k_pre - 1)
+        k_pre += 1
+    wait(k_pre - 1)
     nb = len(batches)
     for k in range(args.warmup * nb):
         enqueue(k)
-        wait(k)
+        if k:
+            wait(k - 1)
+    if args.warmup * nb:
+        wait(args.warmup * nb - 1)
     fence()
     kernel_ms, kernel_frames, kernel_spans = [], [], []
     g.set_profiling(True)  # time zero of the kernel spans: float milliseconds keep their resolution over a short region

@@ -33,16 +33,37 @@ spans = []
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if ours(r["Kernel_Name"]):
-            spans.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-trace = None
-if spans:
+            spans.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+spans.sort()
+bench = None
+for ln in open(os.path.join(out, "stats.log")):
+    if ln.startswith("{"):
+        bench = json.loads(ln)
+
+
+def overlap_stats(sp):
     union, end = 0, -1
-    for t0, t1 in sorted(spans):
+    for t0, t1, _ in sp:
         if t1 > end:
             union += t1 - max(t0, end)
             end = t1
-    total = sum(t1 - t0 for t0, t1 in spans)
-    trace = {"launches": len(spans), "sum_ns": total, "union_ns": union, "launches_in_flight": total / union}
+    total = sum(t1 - t0 for t0, t1, _ in sp)
+    per = collections.defaultdict(list)
+    for t0, t1, k in sp:
+        per[k].append(t1 - t0)
+    return {"launches": len(sp), "sum_ns": total, "union_ns": union, "launches_in_flight": total / union,
+            "avg_ns": {k: sum(v) / len(v) for k, v in per.items()}}
+
+
+trace = None
+if spans:
+    trace = {"all": overlap_stats(spans)}  # pre-roll and warmup included (what kernel_stats.csv averages over)
+    if bench:  # the launches of the timed steps: the last steps x batches per step x launches per batch of the run
+        cfgb, roof = bench["config"], bench["roofline"]
+        n_timed = int(round(bench["steps"] * cfgb["frames_per_step"] / bench["n_gpus"] / cfgb["frames_per_batch"])) * int(roof["launches_per_batch"])
+        if 0 < n_timed <= len(spans):
+            trace["timed_steps"] = overlap_stats(spans[-n_timed:])
+            trace["timed_steps"]["union_ms_per_batch"] = trace["timed_steps"]["union_ns"] / 1e6 / (n_timed / int(roof["launches_per_batch"]))
 for pas in ("fetch", "write", "grbm", "sq1", "sq2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(out, pas, "**", "*counter_collection.csv"), recursive=True):
@@ -56,10 +77,6 @@ for pas in ("fetch", "write", "grbm", "sq1", "sq2"):
         for c, v in cs.items():
             d[c] = sum(v) / len(v)
             d[c + "_n"] = len(v)
-bench = None
-for ln in open(os.path.join(out, "stats.log")):
-    if ln.startswith("{"):
-        bench = json.loads(ln)
 lib = os.path.join(ROOT, "image_processing_amd", "lib", "libimgproc_hip.so")
 sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
 sys.path.insert(0, ROOT)

@@ -57,7 +57,8 @@ def main():
         out[cfg] = {"frames_per_launch": frames, "hbm_bytes_per_launch": hbm, "valu_insts_per_launch": valu,
                     "clock_ghz": (sum(g * t for g, t in ghzs) / sum(t for _, t in ghzs)) if ghzs else None,  # time-weighted
                     "cheap_class_share": classes.get(cfg, {}).get("cheap_class_share"),
-                    "launches_in_flight": (d.get("kernel_trace") or {}).get("launches_in_flight"),
+                    "launches_in_flight": ((d.get("kernel_trace") or {}).get("timed_steps") or {}).get("launches_in_flight"),
+                    "trace_union_ms_per_batch": ((d.get("kernel_trace") or {}).get("timed_steps") or {}).get("union_ms_per_batch"),
                     "lib_sha16": d.get("lib_sha16"), "src_sha16": d.get("src_sha16"), "kernels": kernels}
     json.dump(out, open(os.path.join(PROF, "r03_pmc_summary.json"), "w"), indent=1)
     for cfg, v in out.items():
