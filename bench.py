@@ -59,7 +59,7 @@ def config_table():
 
     bands = [(20 * i, 20 * i + 19) for i in range(8)]
     return {
-        "c1": dict(w=640, h=480, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+        "c1": dict(w=640, h=480, enc=L.ENC_BGR8, batch=256, in_flight=3, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
                    pipe=dict(morph=ip.MORPH_BASELINE), ranges=[DEFAULT_RANGE], cpu_budget_s=20.0,
                    metric="frames/sec at 640x480 BGR8, HSV inRange + 3x3 erode + 3x3 dilate + centroid (no blur)",
                    workload="configs[0] (the reference's CPU-runnable case, pose_estimate.cpp:203-206,405-415 with one erode and one "
@@ -83,13 +83,13 @@ def config_table():
                             "cycled) cut into contiguous per-rank blocks by shard_bounds, device batches of 64 frames, two in "
                             "flight; per-frame centroids gathered on rank 0 by frame id after the timed region"),
         # not BASELINE configs: the reference nodes' own chains at the headline frame shape (two launches per batch)
-        "pp": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+        "pp": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, in_flight=3, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
                    pipe=dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH), ranges=[DEFAULT_RANGE],
                    metric="frames/sec at 1920x1200 BGR8, polygon_path chain (3x3 Gaussian, HSV, 5x5 Gaussian, inRange, 14 erode/dilate, moments)",
                    workload="objectPolygonPath.cpp:182-188,414-433 at 1920x1200 BGR8, device-resident batch of 256 frames per GPU per "
                             "step: front kernel (blur3, HSV, blur5, inRange -> bit planes) + bit-plane morphology (E3x4 D8x2 E3x2 D8x2 "
                             "E3x4 merged into 5 windows, moments, mask bytes)"),
-        "pe": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
+        "pe": dict(w=1920, h=1200, enc=L.ENC_BGR8, batch=256, in_flight=3, uniq=8, bpp=4, scaling="weak", hue_bands=((100, 130),),
                    pipe=dict(post_blur_k=5, morph=ip.MORPH_POSE_ESTIMATE), ranges=[DEFAULT_RANGE],
                    metric="frames/sec at 1920x1200 BGR8, pose_estimate chain with its blur and morphOps enabled",
                    workload="pose_estimate.cpp:203-206,405-415 (commented lines enabled) at 1920x1200 BGR8, device-resident batch of 256 "
@@ -350,7 +350,10 @@ def run_rank(args) -> None:
         frames[i] = torch.roll(base[i % uniq], (2 if cn == 1 else 1) * (i // uniq), dims=0)  # even shifts keep the mosaic phase
     masks = torch.empty((pool_n, nr, H, W), dtype=torch.uint8, device=dev)
     # with ticket 1 on a stream of its own the two batches in flight write at the same time: one mask buffer each
-    masks_b = torch.empty_like(masks)
+    # device batches in flight (tickets of the C ABI): 2, or 3 where measured better (the two-launch chains and the small frames
+    # of c1: profiles/r03_in_flight_sweep.log); 4 is slower everywhere
+    DEPTH = max(1, min(L.MAX_TICKETS, int(os.environ.get("BENCH_IN_FLIGHT", cfg.get("in_flight", 2)))))
+    mask_bufs = [masks] + [torch.empty_like(masks) for _ in range(DEPTH - 1)]
     torch.cuda.synchronize()
     frame_bytes, row_bytes = H * W * cn, W * cn
 
@@ -362,14 +365,14 @@ def run_rank(args) -> None:
 
     # the C ABI fills these host arrays with the per-frame moments / centroids; two, because two batches are in flight:
     # batch k+1 is put on the stream before batch k's results are waited for, so the GPU never idles between them
-    raws = [(L.Result * pool_n)(), (L.Result * pool_n)()]
+    raws = [(L.Result * pool_n)() for _ in range(DEPTH)]
 
     def enqueue(k):
         off, n, _ = batches[k % len(batches)]
-        g.batch_enqueue(k & 1, frames.data_ptr() + off * frame_bytes, frame_bytes, row_bytes, W, H, n, (masks_b if k & 1 else masks).data_ptr())
+        g.batch_enqueue(k % DEPTH, frames.data_ptr() + off * frame_bytes, frame_bytes, row_bytes, W, H, n, mask_bufs[k % DEPTH].data_ptr())
 
     def wait(k):
-        return g.batch_wait(k & 1, raw=raws[k & 1])
+        return g.batch_wait(k % DEPTH, raw=raws[k % DEPTH])
 
     def fence():
         g.synchronize()
@@ -381,20 +384,22 @@ def run_rank(args) -> None:
     # a 23-step run and 0.78 ms from the ~40th step on).  The metric is steady-state throughput, so the device is kept
     # busy with the same work for PREROLL_S before the W warmup steps; nothing of it is timed or reported.
     t_pre = time.perf_counter()
-    enqueue(0)
-    k_pre = 1
-    while time.perf_counter() - t_pre < PREROLL_S:  # the same two-in-flight pattern as the timed loop
+    k_pre = 0
+    while time.perf_counter() - t_pre < PREROLL_S or k_pre < DEPTH:  # the same in-flight pattern as the timed loop
         enqueue(k_pre)
-        wait(k_pre - 1)
+        if k_pre >= DEPTH - 1:
+            wait(k_pre - DEPTH + 1)
         k_pre += 1
-    wait(k_pre - 1)
+    for k in range(max(0, k_pre - DEPTH + 1), k_pre):
+        wait(k)
     nb = len(batches)
-    for k in range(args.warmup * nb):
+    n_warm = args.warmup * nb
+    for k in range(n_warm):
         enqueue(k)
-        if k:
-            wait(k - 1)
-    if args.warmup * nb:
-        wait(args.warmup * nb - 1)
+        if k >= DEPTH - 1:
+            wait(k - DEPTH + 1)
+    for k in range(max(0, n_warm - DEPTH + 1), n_warm):
+        wait(k)
     fence()
     kernel_ms, kernel_frames, kernel_spans = [], [], []
     g.set_profiling(True)  # time zero of the kernel spans: float milliseconds keep their resolution over a short region
@@ -416,9 +421,10 @@ def run_rank(args) -> None:
     t0 = time.perf_counter()
     for k in range(total):  # every batch's results reach the host inside the timed region
         enqueue(k)
-        if k:
-            collect(k - 1)
-    collect(total - 1)
+        if k >= DEPTH - 1:
+            collect(k - DEPTH + 1)
+    for k in range(max(0, total - DEPTH + 1), total):
+        collect(k)
     g.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -450,7 +456,7 @@ def run_rank(args) -> None:
         morph = [(m.kind, m.shape, m.kw, m.kh, -1, -1) for m in pipe["morph"]]
         exp = Oracle(fast=True).chain(f, encoding=enc, pre_blur_k=pipe.get("pre_blur_k", 0), post_blur_k=pipe.get("post_blur_k", 0),
                                       morph=morph, ranges=cfg["ranges"], stages=False)
-        got = (masks_b if (total - 1) & 1 else masks)[i].cpu().numpy()
+        got = mask_bufs[(total - 1) % DEPTH][i].cpu().numpy()
         for r in range(nr):
             assert (got[r] == exp["mask"][r]).all(), f"bench mask of range {r} != oracle"
             idx = batches[-1][2] - a + i
@@ -523,8 +529,9 @@ def run_rank(args) -> None:
             "metric": cfg["metric"], "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": cfg["workload"] + "; two batches in flight (results of batch k are collected after batch k+1 "
-                                                    "is enqueued)",
+            "config": {"workload": cfg["workload"] + f"; {DEPTH} batches in flight, each on its own stream (results of batch k are "
+                                                    f"collected after batch k+{DEPTH - 1} is enqueued)",
+                       "batches_in_flight": DEPTH,
                        "name": args.config, "checked": checked, "frames_per_step": frames_per_step_total, "frames_per_batch": pool_n, "width": W,
                        "height": H, "n_ranges": nr, "untimed_preroll_s": PREROLL_S,
                        "path": plan if not args.unfused else f"stage-by-stage ({launches} launches per batch)",

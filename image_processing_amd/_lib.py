@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libimgproc_hip.so")
 
 MAX_RANGES, MAX_MORPH, MAX_KSIZE = 8, 32, 31
+MAX_TICKETS = 4  # device batches in flight per context
 OK, EINVAL, ENOMEM, EHIP, ESTATE, ESIZE, ENODEV, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 ENC_BGR8, ENC_RGB8, ENC_BAYER_RGGB8 = 0, 1, 2
 ERODE, DILATE = 0, 1

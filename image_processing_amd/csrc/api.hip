@@ -214,12 +214,13 @@ struct imgproc_ctx {
         hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
         bool pending = false, timed = false;
         int n = 0, nr = 0, launches = 0, second = 0;
-    } batch[2];
+    } batch[IMGPROC_MAX_TICKETS];
     int last_ticket = -1;  // the batch imgproc_last_kernel_ms reports on
     // inRange planes of a device batch for the front + bit-plane path (grown on demand), one buffer per ticket
-    u8 *d_thresh_batch[2] = {nullptr, nullptr};
-    size_t thresh_batch_bytes[2] = {0, 0};
-    hipStream_t stream2 = nullptr;  // ticket 1 of the one- and two-launch batch paths runs here (IMGPROC_BATCH_STREAMS=1: off)
+    u8 *d_thresh_batch[IMGPROC_MAX_TICKETS] = {};
+    size_t thresh_batch_bytes[IMGPROC_MAX_TICKETS] = {};
+    // tickets 1.. of the one- and two-launch batch paths run on streams of their own (IMGPROC_BATCH_STREAMS=1: all on `stream`)
+    hipStream_t tstream[IMGPROC_MAX_TICKETS] = {};
     hipEvent_t ev_ref = nullptr;    // time zero of imgproc_last_kernel_span (re-recorded by imgproc_set_profiling)
     unsigned char *na_scratch = nullptr;    // this device's copy of `scratch` (hipGetSymbolAddress at create)
     unsigned long long *h_na_mom = nullptr;  // pinned landing buffer of the no-allocation entry point (max_batch frames)
@@ -598,7 +599,8 @@ IMGPROC_API int imgproc_create(imgproc_ctx **out, const imgproc_config *cfg)
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         // ticket 1 of the device-batch path gets a stream of its own unless IMGPROC_BATCH_STREAMS=1 (A/B: DESIGN.md 4)
         const char *bs = getenv("IMGPROC_BATCH_STREAMS");
-        if (!bs || atoi(bs) != 1) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (!bs || atoi(bs) != 1)
+            for (int t = 1; t < IMGPROC_MAX_TICKETS; t++) HIPCHK(c, hipStreamCreateWithFlags(&c->tstream[t], hipStreamNonBlocking));
         HIPCHK(c, hipEventCreate(&c->ev_ref));
         HIPCHK(c, hipEventRecord(c->ev_ref, c->stream));
         // HSV reciprocal tables: cvRound == round-half-even == lrint
@@ -668,7 +670,8 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (hipStream_t t : c->tstream)
+        if (t) (void)hipStreamSynchronize(t);
     for (auto &s : c->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         free_slot(s);
@@ -690,7 +693,8 @@ IMGPROC_API void imgproc_destroy(imgproc_ctx *c)
         if (b.ev_done) (void)hipEventDestroy(b.ev_done);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (hipStream_t t : c->tstream)
+        if (t) (void)hipStreamDestroy(t);
     if (c->ev_ref) (void)hipEventDestroy(c->ev_ref);
     delete c->copy_pool;
     delete c;
@@ -1030,7 +1034,7 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
                                       int w, int h, int n, void *d_masks, int ticket)
 {
     if (!c || !d_frames || n < 0) return IMGPROC_EINVAL;
-    if (ticket < 0 || ticket > 1) return fail(c, IMGPROC_EINVAL, "ticket %d (0 or 1)", ticket);
+    if (ticket < 0 || ticket >= IMGPROC_MAX_TICKETS) return fail(c, IMGPROC_EINVAL, "ticket %d (0..%d)", ticket, IMGPROC_MAX_TICKETS - 1);
     if (n > c->cfg.max_batch) return fail(c, IMGPROC_ESIZE, "batch %d > max_batch %d", n, c->cfg.max_batch);
     imgproc_ctx::Batch &bt = c->batch[ticket];
     if (bt.pending) return fail(c, IMGPROC_ESTATE, "ticket %d is still in flight: imgproc_batch_wait first", ticket);
@@ -1061,8 +1065,9 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
                              ipk::gauss_fused_ok((const u8 *)d_frames, frame_stride, row_stride, w, h, p.post, p.bounds);
     // Paths that touch nothing of the context but read-only tables and this ticket's own buffers may run ticket 1 on a
     // stream of its own (default; IMGPROC_BATCH_STREAMS=1 turns it off), so kernels of consecutive batches overlap on the GPU.
-    hipStream_t const st = (c->stream2 && ticket == 1 && (one_launch || two_launch || group_fused)) ? c->stream2 : c->stream;
-    const bool overlapped = c->stream2 && c->batch[ticket ^ 1].pending;  // the other ticket's kernels run beside this batch's
+    hipStream_t const st = (c->tstream[ticket] && (one_launch || two_launch || group_fused)) ? c->tstream[ticket] : c->stream;
+    bool overlapped = false;  // another ticket's kernels run beside this batch's
+    for (int t = 0; t < IMGPROC_MAX_TICKETS; t++) overlapped |= t != ticket && c->batch[t].pending && c->tstream[1];
     u8 *&planes = c->d_thresh_batch[ticket];
     size_t &planes_bytes = c->thresh_batch_bytes[ticket];
     auto grow_planes = [&](size_t need) -> int {  // grown on demand, kept for the life of the context; only this ticket uses it
@@ -1143,7 +1148,7 @@ IMGPROC_API int imgproc_batch_enqueue(imgproc_ctx *c, const void *d_frames, size
 IMGPROC_API int imgproc_batch_wait(imgproc_ctx *c, int ticket, imgproc_result *out)
 {
     if (!c) return IMGPROC_EINVAL;
-    if (ticket < 0 || ticket > 1) return fail(c, IMGPROC_EINVAL, "ticket %d (0 or 1)", ticket);
+    if (ticket < 0 || ticket >= IMGPROC_MAX_TICKETS) return fail(c, IMGPROC_EINVAL, "ticket %d (0..%d)", ticket, IMGPROC_MAX_TICKETS - 1);
     imgproc_ctx::Batch &bt = c->batch[ticket];
     if (!bt.pending) return fail(c, IMGPROC_ESTATE, "ticket %d holds no batch", ticket);
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1494,7 +1499,8 @@ IMGPROC_API int imgproc_synchronize(imgproc_ctx *c)
     if (!c) return IMGPROC_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    for (hipStream_t t : c->tstream)
+        if (t) HIPCHK(c, hipStreamSynchronize(t));
     for (auto &s : c->slots) HIPCHK(c, hipStreamSynchronize(s.stream));
     return IMGPROC_OK;
 }

@@ -226,7 +226,8 @@ class ImgProc:
 
     def batch_enqueue(self, ticket: int, d_frames: int, frame_stride: int, row_stride: int, w: int, h: int, n: int,
                       d_masks: int | None = None):
-        """Puts a device batch on the stream and returns; two tickets (0, 1) may be in flight."""
+        """Puts a device batch on its ticket's stream and returns; tickets 0 .. L.MAX_TICKETS - 1 may be in flight, their
+        d_masks must not overlap."""
         self._chk(self.lib.imgproc_batch_enqueue(self._ctx, d_frames, frame_stride, row_stride, w, h, n, d_masks, ticket),
                   "imgproc_batch_enqueue")
 

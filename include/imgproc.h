@@ -32,6 +32,7 @@ extern "C" {
 #define IMGPROC_MAX_RANGES 8
 #define IMGPROC_MAX_MORPH 32
 #define IMGPROC_MAX_KSIZE 31
+#define IMGPROC_MAX_TICKETS 4 /* device batches in flight per context (imgproc_batch_enqueue) */
 
 typedef struct imgproc_ctx imgproc_ctx;
 
@@ -157,13 +158,14 @@ int imgproc_process_batch(imgproc_ctx *ctx, const uint8_t *frames, size_t frame_
  * d_masks (may be NULL) receives [n][n_ranges][h][w] final masks, out (host) receives n results. */
 int imgproc_process_batch_device(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride, size_t row_stride,
                                  int w, int h, int n, void *d_masks, imgproc_result *out);
-/* The same in two halves, so that two device batches can be in flight (offline bag processing, the benchmark):
- * enqueue puts batch `ticket` (0 or 1) on a stream of the context and returns; wait blocks until it is done and fills
- * out[n] (out may be NULL).  d_frames / d_masks must stay valid until the wait.  The two tickets are independent of
- * each other: pipelines that run as one or two launches per batch put ticket 1 on a stream of its own, so its kernels
- * overlap ticket 0's on the GPU (3-16 % more frames/s than one stream; IMGPROC_BATCH_STREAMS=1 in the
- * environment at imgproc_create keeps both on one stream) -- the d_masks of two batches in flight must therefore not
- * overlap, and neither batch may read what the other writes.  process_batch_device is enqueue(ticket 0) + wait(0).
+/* The same in two halves, so that several device batches can be in flight (offline bag processing, the benchmark):
+ * enqueue puts batch `ticket` (0 .. IMGPROC_MAX_TICKETS - 1) on a stream of the context and returns; wait blocks until
+ * it is done and fills out[n] (out may be NULL).  d_frames / d_masks must stay valid until the wait.  Tickets are
+ * independent of each other: pipelines that run as one or two launches per batch put every ticket on a stream of its
+ * own, so the kernels of batches in flight overlap on the GPU (two in flight: 3-16 % more frames/s than one stream,
+ * DESIGN.md 4; three help the two-launch chains a little more, four are slower; IMGPROC_BATCH_STREAMS=1 in the
+ * environment at imgproc_create keeps all tickets on one stream) -- the d_masks of batches in flight must therefore
+ * not overlap, and no batch may read what another writes.  process_batch_device is enqueue(ticket 0) + wait(0).
  * Like it, these have no call site in the reference (its nodes see one frame at a time). */
 int imgproc_batch_enqueue(imgproc_ctx *ctx, const void *d_frames, size_t frame_stride, size_t row_stride, int w, int h,
                           int n, void *d_masks, int ticket);

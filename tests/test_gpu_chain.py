@@ -486,26 +486,34 @@ def test_two_tickets_overlap_on_two_streams(gpu, oracle, preset):
         ref_b = gpu.process_batch_device(d_b, w * h * cn, w * cn, w, h, n, d_ma)
         mask_b = gpu.dev_download(d_ma, (n, nr, h, w)).copy()
         assert ref_a != ref_b
-        gpu.set_profiling(True)
-        spans = []
-        gpu.batch_enqueue(0, d_a, w * h * cn, w * cn, w, h, n, d_ma)
-        for k in range(1, 8):  # ticket k & 1 takes batch A on even k, B on odd k; batch k - 1 is collected after k is enqueued
-            gpu.batch_enqueue(k & 1, d_b if k & 1 else d_a, w * h * cn, w * cn, w, h, n, d_mb if k & 1 else d_ma)
-            assert gpu.batch_wait((k - 1) & 1, n=n) == (ref_b if (k - 1) & 1 else ref_a)
-            spans.append(gpu.last_kernel_span())
-        assert gpu.batch_wait(1, n=n) == ref_b
-        spans.append(gpu.last_kernel_span())
-        gpu.set_profiling(False)
-        assert (gpu.dev_download(d_ma, (n, nr, h, w)) == mask_a).all()
-        assert (gpu.dev_download(d_mb, (n, nr, h, w)) == mask_b).all()
-        assert all(0 <= t0 < t1 for t0, t1 in spans) and all(b[1] > a[1] for a, b in zip(spans, spans[2:]))  # same ticket: in order
+        d_m = [d_ma, d_mb, gpu.dev_alloc(n * nr * w * h)]
+        for depth in (2, 3):  # batch k is A on even k, B on odd k, on ticket k % depth; collected after batch k + depth - 1 is enqueued
+            gpu.set_profiling(True)
+            spans = []
+            for k in range(9):
+                gpu.batch_enqueue(k % depth, d_b if k & 1 else d_a, w * h * cn, w * cn, w, h, n, d_m[k % depth])
+                if k >= depth - 1:
+                    j = k - depth + 1
+                    assert gpu.batch_wait(j % depth, n=n) == (ref_b if j & 1 else ref_a), (depth, j)
+                    spans.append(gpu.last_kernel_span())
+            for j in range(9 - depth + 1, 9):
+                assert gpu.batch_wait(j % depth, n=n) == (ref_b if j & 1 else ref_a), (depth, j)
+                spans.append(gpu.last_kernel_span())
+            gpu.set_profiling(False)
+            for t in range(depth):  # the last batch each ticket took: k = 8, 7 (, 6)
+                k = max(j for j in range(9) if j % depth == t)
+                assert (gpu.dev_download(d_m[t], (n, nr, h, w)) == (mask_b if k & 1 else mask_a)).all(), (depth, t)
+            assert all(0 <= t0 < t1 for t0, t1 in spans)
+            assert all(b[1] > a[1] for a, b in zip(spans, spans[depth:]))  # one ticket's batches run in order
+        with pytest.raises(ip.ImgProcError):
+            gpu.batch_enqueue(L.MAX_TICKETS, d_a, w * h * cn, w * cn, w, h, n, d_ma)
         exp = oracle.chain(fb[1], encoding=L.ENC_BAYER_RGGB8 if bayer else L.ENC_BGR8, morph=morph_tuples(kw["morph"]), ranges=ranges,
                            stages=False, **{k: v for k, v in kw.items() if k != "morph"})
         for r in range(nr):
             assert (mask_b[1, r] == exp["mask"][r]).all()
             check_moments(ref_b[1][r], exp["moments"][r])
     finally:
-        for p in (d_a, d_b, d_ma, d_mb):
+        for p in [d_a, d_b] + (d_m if "d_m" in locals() else [d_ma, d_mb]):
             gpu.dev_free(p)
 
 
