@@ -42,6 +42,18 @@ with ip.ImgProc(1024, 256, n_slots=1, max_batch=1) as gpu:
                 gb.dev_upload(d_in, frames)
                 rb = gb.process_batch_device(d_in, frames[0].nbytes, frames.strides[1], w, h, 3, d_out)
                 mb = gb.dev_download(d_out, (3, nr, h, w))
+                # the same batch on tickets 1 and 2 at once (streams of their own, planes of their own)
+                d_t = [gb.dev_alloc(3 * nr * w * h) for _ in range(2)]
+                try:
+                    for t in (1, 2):
+                        gb.batch_enqueue(t, d_in, frames[0].nbytes, frames.strides[1], w, h, 3, d_t[t - 1])
+                    for t in (2, 1):
+                        if gb.batch_wait(t, n=3) != rb or not (gb.dev_download(d_t[t - 1], (3, nr, h, w)) == mb).all():
+                            bad += 1
+                            print("TICKET MISMATCH seed", seed, "ticket", t, gb.plan, f.shape, c["pre"], c["post"], flush=True)
+                finally:
+                    for q in d_t:
+                        gb.dev_free(q)
             finally:
                 gb.dev_free(d_in); gb.dev_free(d_out)
         for r in range(nr):
