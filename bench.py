@@ -463,6 +463,17 @@ def run_rank(args) -> None:
             assert [int(v) for v in local[idx, r]] == [int(v) for v in exp["moments"][r][:3]], "bench moments != oracle"
         checked = True
 
+    # The classical per-launch figure beside the overlapped one: the first batch a few times, one at a time (nothing else on
+    # the GPU), HIP events around its kernels.  After the timed region and the check: `value` does not see it.
+    alone_ms = []
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PREROLL_S or len(alone_ms) < 12:  # the clocks have dropped during the check: same pre-roll
+        enqueue(0)
+        wait(0)
+        alone_ms.append(g.last_kernel_ms()[0])
+    alone_ms = alone_ms[-12:]
+    alone_frames = batches[0][1]
+
     if rank == 0:
         fps = frames_per_step_total * args.steps / dt
         ms_sum = float(sum(m for m, _ in kernel_ms))
@@ -485,6 +496,12 @@ def run_rank(args) -> None:
                 "kernel": kernel_name(cfg, plan), "kernel_ms_per_launch": k_ms if fused else None,
                 "kernel_ms_per_batch": k_ms, "launches_per_batch": launches,
                 "batches_in_flight": in_flight, "kernel_ms_per_batch_effective": k_eff,
+                "one_batch_at_a_time": {"kernel_ms_per_batch": sum(alone_ms) / len(alone_ms),
+                                        "achieved": algo_bytes * alone_frames / (sum(alone_ms) / len(alone_ms) * 1e-3) / 1e9,
+                                        "frac": algo_bytes * alone_frames / (sum(alone_ms) / len(alone_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                        "note": "the same batch with nothing else in flight (the last 12 of a 0.15 s run of single batches after the timed region, HIP events "
+                                                "around the kernels of each): bytes / launch duration in the plain sense; alone the chain "
+                                                "kernel is cut into ~100-row segments, overlapped into ~300-row ones"},
                 "timing": "HIP events around each batch's kernels on the batch's own stream (kernel_ms_per_batch = average span, what "
                           "rocprofv3 --kernel-trace --stats reports per launch); consecutive batches run on two streams and overlap on "
                           "the GPU, so achieved = algorithmic bytes of all batches / union of the spans "
