@@ -62,10 +62,10 @@ def test_config4_3840x2160_batch(oracle):
 
 
 def test_config5_stress_7680x4320():
-    """configs[4]: 7680x4320, 15x15 Gaussian + 9x9 elliptical erode/dilate + 8 simultaneous ranges.  The CPU oracle needs
-    minutes at this size, so the check is: the bit-plane path and the per-op stage kernels (two independent GPU
-    implementations of the morphology, both parity-tested against the oracle at small sizes) agree bit for bit, and the
-    moments equal the sums over the masks."""
+    """configs[4]: 7680x4320, 15x15 Gaussian + 9x9 elliptical erode/dilate + 8 simultaneous ranges: the bit-plane path
+    (fused HSV + Gaussian + inRange kernel, strip morphology) and the per-op stage kernels (two independent GPU
+    implementations) agree bit for bit, the moments equal the sums over the masks, and all eight masks and moment sets
+    equal the oracle's on the full frame."""
     w, h = 7680, 4320
     bands = [(20 * i, 20 * i + 19) for i in range(8)]
     f = synth_frame(w, h, 3, hue_bands=bands)
@@ -86,6 +86,12 @@ def test_config5_stress_7680x4320():
         assert [res_a[r][k] for k in KEYS] == [res_b[r][k] for k in KEYS] == mask_sums(masks_a[r])
         hit += res_a[r]["m00"] > 0
     assert hit >= 4
+    # and the oracle itself on the full frame (the -O3 build of the same C source: integer arithmetic, ~25 s on one core)
+    from oracle import Oracle
+    exp = Oracle(fast=True).chain(f, post_blur_k=15, morph=morph_tuples(morph), ranges=ranges, stages=False)
+    for r in range(8):
+        assert (masks_a[r] == exp["mask"][r]).all(), r
+        assert [res_a[r][k] for k in KEYS] == [int(v) for v in exp["moments"][r][:3]], r
 
 
 @pytest.mark.parametrize("case", [("bgr", 1920, 1200), ("bgr", 1918, 1203), ("bayer", 2448, 2048)])
