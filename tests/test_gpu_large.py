@@ -217,39 +217,51 @@ def test_submit_pinned_skips_the_staging_copy(oracle, padded, preset):
     assert [got[4][0][0][k] for k in ("m00", "m10", "m01", "m20", "m11", "m02")] == [int(v) for v in exp["moments"][0]]
 
 
-@pytest.mark.parametrize("preset", ["baseline", "polygon_path"])
-def test_overlapped_batches_take_tall_segments(oracle, preset):
-    """With the other ticket in flight a large batch is cut into ~300-row segments instead of ~100-row ones
-    (fused.hip, launch_fused `overlapped`): 96 frames of 1920x1200 structured noise on ticket 1 while ticket 0 runs, equal
-    to the same batch processed alone (other segment borders) mask for mask, and to the oracle on one frame."""
-    w, h, n, uniq = 1920, 1200, 96, 3
+@pytest.mark.parametrize("case", [("baseline", 1920, 1200, 96), ("polygon_path", 1920, 1200, 96), ("baseline", 1918, 1203, 96),
+                                  ("bayer", 2448, 2048, 56)])
+def test_overlapped_batches_take_tall_segments(oracle, case):
+    """With another ticket in flight a large batch is cut into ~300-row segments instead of ~100-row ones
+    (fused.hip, launch_fused `overlapped`): a batch of structured noise on tickets 1 and 2 while ticket 0 runs, equal to the
+    same batch processed alone (other segment borders) mask for mask, and to the oracle on one frame.  Chain kernel, front
+    kernel, a width that is not a multiple of 4 with a height that does not divide, and the Bayer chain."""
+    preset, w, h, n = case
+    uniq = 3
+    bayer = preset == "bayer"
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:h, 0:w]
     blob = (np.sin(xx / 41.0) * np.cos(yy / 23.0)) > 0.1
-    base = [np.where(blob[:, :, None], rng.integers(0, 256, (h, w, 3), dtype=np.uint8), 40).astype(np.uint8) for _ in range(uniq)]
-    frames = np.stack([np.roll(base[i % uniq], 7 * (i // uniq), axis=0) for i in range(n)])
-    kw = dict(baseline=dict(post_blur_k=5, morph=ip.MORPH_BASELINE),
+    if bayer:
+        base = [np.where(blob, rng.integers(0, 256, (h, w), dtype=np.uint8), 40).astype(np.uint8) for _ in range(uniq)]
+    else:
+        base = [np.where(blob[:, :, None], rng.integers(0, 256, (h, w, 3), dtype=np.uint8), 40).astype(np.uint8) for _ in range(uniq)]
+    frames = np.stack([np.roll(base[i % uniq], 8 * (i // uniq), axis=0) for i in range(n)])  # even shifts keep the mosaic phase
+    kw = dict(baseline=dict(post_blur_k=5, morph=ip.MORPH_BASELINE), bayer=dict(post_blur_k=5, morph=ip.MORPH_BASELINE),
               polygon_path=dict(pre_blur_k=3, post_blur_k=5, morph=ip.MORPH_POLYGON_PATH))[preset]
+    enc = L.ENC_BAYER_RGGB8 if bayer else L.ENC_BGR8
+    cn = 1 if bayer else 3
     rg = [((0, 30, 60), (120, 256, 256))]
     with ip.ImgProc(w, h, n_slots=1, max_batch=n) as g:
-        g.set_pipeline(**kw)
+        g.set_pipeline(encoding=enc, **kw)
         g.set_ranges(rg)
+        assert "stage kernels" not in g.plan
         d_in = g.dev_alloc(frames.nbytes)
-        d_m = [g.dev_alloc(n * w * h) for _ in range(3)]
+        d_m = [g.dev_alloc(n * w * h) for _ in range(4)]
         try:
             g.dev_upload(d_in, frames)
-            alone = g.process_batch_device(d_in, w * h * 3, w * 3, w, h, n, d_m[0])
-            g.batch_enqueue(0, d_in, w * h * 3, w * 3, w, h, n, d_m[1])
-            g.batch_enqueue(1, d_in, w * h * 3, w * 3, w, h, n, d_m[2])  # ticket 0 pending: overlapped
-            assert g.batch_wait(0, n=n) == alone
-            assert g.batch_wait(1, n=n) == alone
+            alone = g.process_batch_device(d_in, w * h * cn, w * cn, w, h, n, d_m[0])
+            for t in range(3):
+                g.batch_enqueue(t, d_in, w * h * cn, w * cn, w, h, n, d_m[1 + t])  # tickets 1 and 2 see another one pending: overlapped
+            for t in (2, 0, 1):
+                assert g.batch_wait(t, n=n) == alone, t
             m_alone = g.dev_download(d_m[0], (n, h, w))
-            m_over = g.dev_download(d_m[2], (n, h, w))
+            for t in (1, 2):
+                assert (g.dev_download(d_m[1 + t], (n, h, w)) == m_alone).all(), t
         finally:
             g.dev_free(d_in)
             for p in d_m:
                 g.dev_free(p)
-    assert (m_alone == m_over).all()
-    exp = oracle.chain(frames[50], morph=morph_tuples(kw["morph"]), ranges=rg, stages=False, **{k: v for k, v in kw.items() if k != "morph"})
-    assert (m_over[50] == exp["mask"][0]).all()
-    assert [alone[50][0][k] for k in KEYS] == [int(v) for v in exp["moments"][0][:3]] and alone[50][0]["m00"] > 0
+    i = n // 2
+    exp = oracle.chain(frames[i], encoding=enc, morph=morph_tuples(kw["morph"]), ranges=rg, stages=False,
+                       **{k: v for k, v in kw.items() if k != "morph"})
+    assert (m_alone[i] == exp["mask"][0]).all()
+    assert [alone[i][0][k] for k in KEYS] == [int(v) for v in exp["moments"][0][:3]] and alone[i][0]["m00"] > 0
