@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #define ITER 2048
 #define R16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
 // A/B alternate two instruction kinds (even / odd registers); P = A for the first 12, B for the last 4, and so on
@@ -204,7 +205,8 @@ int main(int argc, char **argv)
                   {"mfma_4_valu_8", k_mfma_mix<4, 8>, 12.0}};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
-    const int blocks = prop.multiProcessorCount * 8;
+    const int wps = argc > 2 ? atoi(argv[2]) : 8;  // waves per SIMD (one 256-thread block = one wave on each SIMD of a CU)
+    const int blocks = prop.multiProcessorCount * wps;
     uint32_t *d;
     hipMalloc(&d, (size_t)blocks * 256 * 4);
     hipEvent_t e0, e1;
@@ -221,7 +223,7 @@ int main(int argc, char **argv)
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        const double iters = 5.0 * 8 * ITER;  // per SIMD: 8 waves x ITER iterations x 5 launches
+        const double iters = 5.0 * wps * ITER;  // per SIMD: wps waves x ITER iterations x 5 launches
         printf("%-20s %7.3f ms  %6.1f cycles/iteration/SIMD-wave  %.2f cycles per instruction (2.4 GHz)\n", en.name, ms,
                ms * 1e-3 * 2.4e9 / iters, ms * 1e-3 * 2.4e9 / (iters * en.insts_per_iter));
         fflush(stdout);
