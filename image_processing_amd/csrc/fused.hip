@@ -64,6 +64,7 @@ bool can_launch_fused(const FusedPlan &plan, const void *d_frames, size_t frame_
     // which gfx950 global memory handles (scripts/ubench/unaligned.hip).
     if ((w & 3) && (w < 32 || (plan.bayer && (w & 1)))) return false;
     if (plan.bayer && h < 3) return false;  // no interior row: OpenCV writes zeros, the stage kernel does that
+    if (plan.bayer && w < 8) return false;  // the lanes' 8-byte mosaic windows (fused_kernel.hpp, bayer_window_fix)
     // reflect_row() reflects once: exact BORDER_REFLECT_101 while the blurs' look-ahead (pre 1 + post 2 rows) stays below
     // h; shorter frames take the stage kernels
     if (h < (plan.pre_k == 3 ? 1 : 0) + (plan.post_k == 5 ? 2 : 0) + 1) return false;

@@ -36,8 +36,8 @@ namespace ipf {
 
 using ipk::u8;
 
-constexpr int strip_valid(bool bayer) { return bayer ? 240 : 248; }  // valid output columns per wave: lanes 1..62, or
-                                                                     // 2..61 when the Bayer front end adds a column of reach
+constexpr int strip_valid(bool) { return 248; }  // valid output columns per wave: lanes 1..62 (Bayer too: its lanes load the
+                                                // mosaic columns next to their own four themselves, see demosaic_hsv_row)
 constexpr int MAX_NR = 8;  // kernel variants hold 1, 2, 4 or 8 ranges; a.nr of them are live
 
 struct Args {
@@ -201,16 +201,42 @@ struct Pairs {
     uint32_t b[2], g[2], r[2];
 };
 
-__device__ __forceinline__ void demosaic_row(const uint32_t (&w)[3], bool odd_row, int border_strip, bool first_col,
+// The three mosaic rows arrive as 8-byte windows (w[2i], w[2i+1] = low / high dword of row y-1+i): bytes b0..b7 = columns
+// x0-1 .. x0+6 of the lane's four pixels x0 .. x0+3, so every neighbour a pixel is interpolated from sits in the lane's own
+// registers (v_perm_b32 picks the byte pairs) and no lane depends on its neighbour's load: one halo lane per side is
+// enough, as for BGR input.  Field pair (bx, by) of a window:
+__device__ __forceinline__ uint32_t win_pair(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+constexpr uint32_t WP_E = 0x0C030C01u;  // (b1, b3): the even columns x0, x0+2
+constexpr uint32_t WP_O = 0x0C040C02u;  // (b2, b4): the odd columns x0+1, x0+3
+constexpr uint32_t WP_L = 0x0C020C00u;  // (b0, b2): left neighbours of the even columns
+constexpr uint32_t WP_R = 0x0C050C03u;  // (b3, b5): right neighbours of the odd columns
+
+// Lanes whose window would start before the row (x0 = 0) or end beyond it load the row's first / last 8 bytes instead;
+// this moves the bytes to where the window has them (border strips only; what moves in from outside is never used: the
+// image's border columns copy their neighbours)
+__device__ __forceinline__ void bayer_window_fix(uint32_t &lo_io, uint32_t &hi_io, bool win_lo, int hi_sh8)
+{
+    const uint32_t lo = lo_io, hi = hi_io;
+    if (win_lo) {
+        lo_io = lo << 8;
+        hi_io = alignbit(hi, lo, 24);
+    } else if (hi_sh8) {
+        lo_io = alignbit(hi, lo, hi_sh8);
+        hi_io = hi >> hi_sh8;
+    }
+}
+
+__device__ __forceinline__ void demosaic_row(const uint32_t (&w)[6], bool odd_row, int border_strip, bool first_col,
                                              bool last_col, Pairs &o)
 {
     const uint32_t M8 = 0x00FF00FFu;
-    const uint32_t me = w[1] & M8, mo = (w[1] >> 8) & M8;                                          // centre row
-    const uint32_t vse = (w[0] & M8) + (w[2] & M8), vso = ((w[0] >> 8) & M8) + ((w[2] >> 8) & M8);  // up + down
-    const uint32_t hme = mo + alignbit(mo, from_left(mo), 16);   // left + right of the even columns: cols (-1,1) + (1,3)
-    const uint32_t hmo = me + alignbit(from_right(me), me, 16);  // left + right of the odd columns:  cols (0,2) + (2,4)
+    const uint32_t me = win_pair(w[3], w[2], WP_E), mo = win_pair(w[3], w[2], WP_O);  // centre row
+    const uint32_t vse = win_pair(w[1], w[0], WP_E) + win_pair(w[5], w[4], WP_E);     // up + down
+    const uint32_t vso = win_pair(w[1], w[0], WP_O) + win_pair(w[5], w[4], WP_O);
+    const uint32_t hme = win_pair(w[3], w[2], WP_L) + mo;  // left + right of the even columns
+    const uint32_t hmo = me + win_pair(w[3], w[2], WP_R);  // left + right of the odd columns
     if (!odd_row) {  // R G R G: even columns are R sites, odd columns G with R left/right and B above/below
-        const uint32_t hve = vso + alignbit(vso, from_left(vso), 16);  // the four diagonals of the even columns
+        const uint32_t hve = win_pair(w[1], w[0], WP_L) + win_pair(w[5], w[4], WP_L) + vso;  // the four diagonals of the even columns
         o.r[0] = me;
         o.g[0] = ((hme + vse + 0x00020002u) >> 2) & M8;
         o.b[0] = ((hve + 0x00020002u) >> 2) & M8;
@@ -218,7 +244,7 @@ __device__ __forceinline__ void demosaic_row(const uint32_t (&w)[3], bool odd_ro
         o.r[1] = ((hmo + 0x00010001u) >> 1) & M8;
         o.b[1] = ((vso + 0x00010001u) >> 1) & M8;
     } else {  // G B G B: odd columns are B sites, even columns G with B left/right and R above/below
-        const uint32_t hvo = vse + alignbit(from_right(vse), vse, 16);
+        const uint32_t hvo = vse + win_pair(w[1], w[0], WP_R) + win_pair(w[5], w[4], WP_R);
         o.g[0] = me;
         o.b[0] = ((hme + 0x00010001u) >> 1) & M8;
         o.r[0] = ((vse + 0x00010001u) >> 1) & M8;
@@ -283,18 +309,18 @@ __device__ __forceinline__ uint32_t word_and_x4(uint32_t w)
 // 4 x the rounded average plus junk in bits 0..1, which word_and_x4 drops while it extracts -- one op per value
 // instead of shift + mask per pair and a shift per value.  Arithmetic identical to demosaic_row + hsv_row_pairs:
 // 4 ((a+b+c+d+2) >> 2) = (a+b+c+d+2) & ~3 and 4 ((a+b+1) >> 1) = (2a+2b+2) & ~3.
-__device__ __forceinline__ void demosaic_hsv_row(const uint32_t (&w)[3], bool odd_row, int border_strip, bool first_col,
+__device__ __forceinline__ void demosaic_hsv_row(const uint32_t (&w)[6], bool odd_row, int border_strip, bool first_col,
                                                  bool last_col, const char *tab, Row &o)
 {
-    const uint32_t M8 = 0x00FF00FFu, C2 = 0x00020002u;
-    const uint32_t me = w[1] & M8, mo = __builtin_amdgcn_perm(w[1], w[1], 0x0C030C01u);  // even / odd columns of the centre row
-    const uint32_t vse = (w[0] & M8) + (w[2] & M8);                                        // up + down, even columns
-    const uint32_t vso = __builtin_amdgcn_perm(w[0], w[0], 0x0C030C01u) + __builtin_amdgcn_perm(w[2], w[2], 0x0C030C01u);
-    const uint32_t hme = mo + alignbit(mo, from_left(mo), 16);   // left + right of the even columns
-    const uint32_t hmo = me + alignbit(from_right(me), me, 16);  // left + right of the odd columns
+    const uint32_t C2 = 0x00020002u;
+    const uint32_t me = win_pair(w[3], w[2], WP_E), mo = win_pair(w[3], w[2], WP_O);  // even / odd columns of the centre row
+    const uint32_t vse = win_pair(w[1], w[0], WP_E) + win_pair(w[5], w[4], WP_E);     // up + down, even columns
+    const uint32_t vso = win_pair(w[1], w[0], WP_O) + win_pair(w[5], w[4], WP_O);     // up + down, odd columns
+    const uint32_t hme = win_pair(w[3], w[2], WP_L) + mo;  // left + right of the even columns
+    const uint32_t hmo = me + win_pair(w[3], w[2], WP_R);  // left + right of the odd columns
     uint32_t c4[4][3];  // pixel k: 4b, 4g, 4r (pixel k sits in pair k & 1, field k >> 1)
     if (!odd_row) {  // R G R G: even columns are R sites, odd columns G with R left/right and B above/below
-        const uint32_t hve = vso + alignbit(vso, from_left(vso), 16);  // the four diagonals of the even columns
+        const uint32_t hve = win_pair(w[1], w[0], WP_L) + win_pair(w[5], w[4], WP_L) + vso;  // the four diagonals of the even columns
         const uint32_t g0 = hme + vse + C2, b0 = hve + C2;             // even columns: G, B
         const uint32_t r1 = (hmo << 1) + C2, b1 = (vso << 1) + C2;     // odd columns: R, B
         c4[0][0] = word_and_x4<0>(b0); c4[0][1] = word_and_x4<0>(g0); c4[0][2] = word_x4<0>(me);
@@ -302,7 +328,7 @@ __device__ __forceinline__ void demosaic_hsv_row(const uint32_t (&w)[3], bool od
         c4[1][0] = word_and_x4<0>(b1); c4[1][1] = word_x4<0>(mo); c4[1][2] = word_and_x4<0>(r1);
         c4[3][0] = word_and_x4<1>(b1); c4[3][1] = word_x4<1>(mo); c4[3][2] = word_and_x4<1>(r1);
     } else {  // G B G B: odd columns are B sites, even columns G with B left/right and R above/below
-        const uint32_t hvo = vse + alignbit(from_right(vse), vse, 16);
+        const uint32_t hvo = vse + win_pair(w[1], w[0], WP_R) + win_pair(w[5], w[4], WP_R);
         const uint32_t b0 = (hme << 1) + C2, r0 = (vse << 1) + C2;     // even columns: B, R
         const uint32_t g1 = hmo + vso + C2, r1 = hvo + C2;             // odd columns: G, R
         c4[0][0] = word_and_x4<0>(b0); c4[0][1] = word_x4<0>(me); c4[0][2] = word_and_x4<0>(r0);
@@ -430,7 +456,10 @@ __device__ __forceinline__ uint32_t transpose_nibbles8(uint32_t v, const Transpo
 // kernel holds it as bits anyway, and the back end wants bits (w % 4 == 0 only: strip borders are byte borders then).
 // BAYER: the frames are BayerRG8 mosaics (1 B/px); every fed row loads the three mosaic rows it is interpolated from.
 template <int PRE_K, int POST_K, bool RGB, int NR, int PF, bool M2, int MODE, bool BAYER>
-__global__ __launch_bounds__(256) void k_fused_chain(const Args a)
+// The one-range Bayer chain without pre-blur (BASELINE config 3): the compiler's own allocation is 97 VGPRs, one over the 96
+// that still give 5 waves per SIMD; asked to keep 5 it fits them without scratch (the other Bayer variants would spill)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BAYER && NR == 1 && !M2 && PRE_K == 1 ? 5 : 1)))
+void k_fused_chain(const Args a)
 {
     __shared__ int s_tab[512 + 16];
     s_tab[threadIdx.x] = a.tables[threadIdx.x] * 4;  // 4*sdiv (see hsv_px)
@@ -451,7 +480,7 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     const int w = a.w, h = a.h;
     const int ys = seg * a.seg_rows;
     const int ye = min(ys + a.seg_rows, h);
-    constexpr int HL = BAYER ? 2 : 1;  // halo lanes per side
+    constexpr int HL = 1;  // halo lanes per side
     constexpr int SV = strip_valid(BAYER);
     // Strips are left-aligned (lane columns = 0 mod 4, so the image's left border is a lane boundary) except the last
     // one when w % 4 != 0: that one is right-aligned (a lane boundary at w).  Every strip is then wrong only within
@@ -478,7 +507,11 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
 
     // uniform (SGPR) frame pointer + 32-bit per-lane byte offset: loads use the saddr form
     const u8 *fptr = a.frames + (size_t)frame * a.frame_stride;
-    const uint32_t lane_off = (uint32_t)xl * (BAYER ? 1u : 3u);
+    // Bayer: the lane's 8-byte window starts one column left of its pixels; at the row's ends it is the row's first / last
+    // 8 bytes, shifted into place after the load (bayer_window_fix; w >= 8 is checked at launch)
+    const bool win_lo = BAYER && xl == 0;
+    const int win_hi_sh8 = (BAYER && xl + 7 > w) ? 8 * (xl + 7 - w) : 0;
+    const uint32_t lane_off = BAYER ? (uint32_t)(win_lo ? 0 : win_hi_sh8 ? w - 8 : xl - 1) : (uint32_t)xl * 3u;
     const bool first_col = x0 == 0, last_col = x0 == w - 4;  // Bayer: the image's border columns copy their neighbours
     const uint32_t rs = (uint32_t)a.row_stride;  // byte offsets inside one frame fit 32 bits (checked at launch)
 
@@ -490,34 +523,54 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
     // kept as a scalar integer: as a bool the compiler re-materialises it through a VGPR on every row
     const int border_strip = __builtin_amdgcn_readfirstlane((int)(strip_left || strip_right));  // int, not bool: see above
 
-    uint32_t raw[8][3];
+    // Bayer: the centre rows of consecutive fed rows move by +1 (the usual case), 0 or -1 (the frame's border rows copy
+    // their neighbours; look-ahead beyond the frame reflects), so the three mosaic windows of a fed row are the previous
+    // fed row's, shifted by one: ONE window per fed row is prefetched -- the row that moves in, below or above -- and the
+    // other two stay in registers (bwin).  The segment's first fed row is primed before the prologue.
+    uint32_t raw[8][BAYER ? 2 : 3];
+    uint32_t bwin[6] = {0, 0, 0, 0, 0, 0};  // the previous fed row's windows: above, centre, below
+    int bwin_c = 0;                         // its centre row (uniform)
     Row ring[8];
     RowBGR rawp[PRE_K == 3 ? 8 : 1];
     // raw row in slot `sl` -> HSV row in ring[sl] (with PRE_K == 3: the HSV of the 3x3-blurred row before it)
     auto bayer_row = [&](int f) { return min(max(reflect_row(r_first + f, h), 1), h - 2); };  // border rows copy too
     auto convert = [&](int sl, bool have_rows, int f) {
-        Pairs bp;
-        if (BAYER && PRE_K == 3) demosaic_row(raw[sl], bayer_row(f) & 1, border_strip, first_col, last_col, bp);
-        if (PRE_K == 3) {
-            if (BAYER)
-                pairs_to_row(bp, rawp[sl & (PRE_K == 3 ? 7 : 0)]);
-            else
-                unpack_row(raw[sl], rawp[sl & (PRE_K == 3 ? 7 : 0)]);
+        if constexpr (BAYER) {
+            const int c = bayer_row(f);
+            uint32_t nlo = raw[sl][0], nhi = raw[sl][1];
+            if (border_strip) bayer_window_fix(nlo, nhi, win_lo, win_hi_sh8);
+            if (c > bwin_c) {  // uniform; the usual case: the window below moves in
+                bwin[0] = bwin[2]; bwin[1] = bwin[3]; bwin[2] = bwin[4]; bwin[3] = bwin[5]; bwin[4] = nlo; bwin[5] = nhi;
+            } else if (c < bwin_c) {  // the window above moves in
+                bwin[4] = bwin[2]; bwin[5] = bwin[3]; bwin[2] = bwin[0]; bwin[3] = bwin[1]; bwin[0] = nlo; bwin[1] = nhi;
+            }
+            bwin_c = c;
+        }
+        if constexpr (PRE_K == 3) {
+            if constexpr (BAYER) {
+                Pairs bp;
+                demosaic_row(bwin, bayer_row(f) & 1, border_strip, first_col, last_col, bp);
+                pairs_to_row(bp, rawp[sl & 7]);
+            } else {
+                unpack_row(raw[sl], rawp[sl & 7]);
+            }
             if (have_rows)
-                preblur_hsv_row<RGB>(rawp[(sl + 6) & (PRE_K == 3 ? 7 : 0)], rawp[(sl + 7) & (PRE_K == 3 ? 7 : 0)],
-                                     rawp[sl & (PRE_K == 3 ? 7 : 0)], border_strip, lb_halo, rb_halo, tab, ring[sl]);
-        } else if (BAYER) {
-            demosaic_hsv_row(raw[sl], bayer_row(f) & 1, border_strip, first_col, last_col, tab, ring[sl]);
+                preblur_hsv_row<RGB>(rawp[(sl + 6) & 7], rawp[(sl + 7) & 7], rawp[sl & 7], border_strip, lb_halo, rb_halo, tab, ring[sl]);
+        } else if constexpr (BAYER) {
+            demosaic_hsv_row(bwin, bayer_row(f) & 1, border_strip, first_col, last_col, tab, ring[sl]);
         } else {
             hsv_row<RGB>(raw[sl], tab, ring[sl]);
         }
     };
     auto load_row = [&](int slot, int f) {
-        if (BAYER) {
-            const uint32_t off = (uint32_t)(bayer_row(f) - 1) * rs + lane_off;
-            raw[slot][0] = *reinterpret_cast<const uint32_t *>(fptr + off);
-            raw[slot][1] = *reinterpret_cast<const uint32_t *>(fptr + off + rs);
-            raw[slot][2] = *reinterpret_cast<const uint32_t *>(fptr + off + 2 * rs);
+        if constexpr (BAYER) {
+            // the window that moves in: below the centre when the centre row advances (or at the primed start), above it
+            // when it steps back; 8 bytes at any byte alignment: fine on gfx950 (scripts/ubench/unaligned.hip)
+            const int c = bayer_row(f), cp = f > 0 ? bayer_row(f - 1) : c - 1;
+            const int row = c + (c < cp ? -1 : 1);  // c == cp: loaded and dropped
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(fptr + (uint32_t)row * rs + lane_off);
+            raw[slot][0] = p[0];
+            raw[slot][1] = p[1];
         } else {
             const int r = reflect_row(r_first + f, h);
             const uint32_t off = (uint32_t)r * rs + lane_off;
@@ -546,6 +599,17 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
             if (i < 4) c_hs[i] = out; else c_v[i - 4] = out;
         }
     };
+    if constexpr (BAYER) {  // prime: as if a fed row with centre c0 - 1 had come before (its window above is never used)
+        const int c0 = bayer_row(0);
+        const uint32_t *pm = reinterpret_cast<const uint32_t *>(fptr + (uint32_t)(c0 - 1) * rs + lane_off);
+        const uint32_t *pb = reinterpret_cast<const uint32_t *>(fptr + (uint32_t)c0 * rs + lane_off);
+        bwin[2] = pm[0]; bwin[3] = pm[1]; bwin[4] = pb[0]; bwin[5] = pb[1];
+        if (border_strip) {
+            bayer_window_fix(bwin[2], bwin[3], win_lo, win_hi_sh8);
+            bayer_window_fix(bwin[4], bwin[5], win_lo, win_hi_sh8);
+        }
+        bwin_c = c0 - 1;
+    }
 #pragma unroll
     for (int q = 0; q < PF; q++) load_row((S0 + q) & 7, q);
 #pragma unroll
@@ -659,17 +723,17 @@ __global__ __launch_bounds__(256) void k_fused_chain(const Args a)
         }
         const int yt = t0 + b * 8;  // image row of tile position 0 at the inRange stage
         if (MODE == 2) {
-            // ---- front end, bits out.  Plain input (one halo lane): lane l <- lane l+1, so that lane l stands for columns
-            // base + 4l and every second lane starts a byte of the bitmap (Bayer, two halo lanes: base - 8 + 4l already
-            // does).  Then the 8 lanes of a group trade nibbles so that lane i holds the 32-px word of tile row 7 - i. ----
-            const int li = lane & 7, xg = base - (BAYER ? 8 : 0) + 32 * (lane >> 3);
+            // ---- front end, bits out.  Lane l <- lane l+1, so that lane l stands for columns base + 4l and every second lane
+            // starts a byte of the bitmap.  Then the 8 lanes of a group trade nibbles so that lane i holds the 32-px word of
+            // tile row 7 - i. ----
+            const int li = lane & 7, xg = base + 32 * (lane >> 3);
             const int y = yt + 7 - li;
             const int fb = max(0, (own_lo - xg) >> 3), lb = min(4, (own_hi - xg + 7) >> 3);  // bytes [fb, lb) of the word are this strip's
             const bool store = y >= ys && y < ye && lb > fb;
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 if (NR > 2 && r >= a.nr) break;  // capacity 4 / 8 variants: only a.nr ranges are live
-                const uint32_t word = transpose_nibbles8(BAYER ? acc[r] : from_right(acc[r]), tc);
+                const uint32_t word = transpose_nibbles8(from_right(acc[r]), tc);
                 if (store) {
                     u8 *dst = reinterpret_cast<u8 *>(a.bits + (((size_t)frame * a.nr + r) * h + y) * a.bit_words) + (xg >> 3);
                     if (fb == 0 && lb == 4) {
