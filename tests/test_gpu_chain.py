@@ -160,11 +160,14 @@ def test_fetch_stage_on_demand(gpu, oracle, preset, enc):
     assert gpu.fetch_stage(0, L.STAGE_HSV).shape == (h, w, 3)  # already materialised: still served
 
 
-@pytest.mark.parametrize("hw", [(3, 4), (4, 8), (5, 236), (33, 240), (64, 244), (57, 484), (131, 1000)])
+@pytest.mark.parametrize("hw", [(3, 4), (4, 8), (3, 8), (4, 12), (5, 16), (7, 20), (6, 34), (9, 38), (5, 236), (33, 240), (64, 244),
+                                (33, 248), (17, 252), (12, 256), (21, 260), (19, 250), (57, 484), (40, 496), (40, 500), (31, 746),
+                                (131, 1000)])
 @pytest.mark.parametrize("preset", ["pose_estimate", "baseline", "polygon_path"])
 def test_bayer_front_end_noise(gpu, oracle, hw, preset):
     """The Bayer front end inside the chain / front kernels on full-range noise mosaics (every demosaiced value matters:
-    no blur in `pose_estimate`, two ranges, one of them narrow), sizes around the 240-column strip of the Bayer variant."""
+    no blur in `pose_estimate`, two ranges, one of them narrow): sizes around the 248-column strip, rows of 8 to 20 bytes
+    (every lane's 8-byte window touches a row end), widths with w % 4 == 2 (right-aligned last strip), 3 to 7 rows."""
     h, w = hw
     raw = np.random.default_rng(h * 7919 + w).integers(0, 256, (h, w), dtype=np.uint8)
     ranges = [((0, 40, 60), (90, 256, 256)), ((85, 0, 100), (140, 200, 220))]
