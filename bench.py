@@ -467,7 +467,7 @@ def run_rank(args) -> None:
     # the GPU), HIP events around its kernels.  After the timed region and the check: `value` does not see it.
     alone_ms = []
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < PREROLL_S or len(alone_ms) < 12:  # the clocks have dropped during the check: same pre-roll
+    while args.alone and (time.perf_counter() - t_pre < PREROLL_S or len(alone_ms) < 12):  # the clocks have dropped during the check: same pre-roll
         enqueue(0)
         wait(0)
         alone_ms.append(g.last_kernel_ms()[0])
@@ -496,7 +496,7 @@ def run_rank(args) -> None:
                 "kernel": kernel_name(cfg, plan), "kernel_ms_per_launch": k_ms if fused else None,
                 "kernel_ms_per_batch": k_ms, "launches_per_batch": launches,
                 "batches_in_flight": in_flight, "kernel_ms_per_batch_effective": k_eff,
-                "one_batch_at_a_time": {"kernel_ms_per_batch": sum(alone_ms) / len(alone_ms),
+                "one_batch_at_a_time": None if not alone_ms else {"kernel_ms_per_batch": sum(alone_ms) / len(alone_ms),
                                         "achieved": algo_bytes * alone_frames / (sum(alone_ms) / len(alone_ms) * 1e-3) / 1e9,
                                         "frac": algo_bytes * alone_frames / (sum(alone_ms) / len(alone_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                         "note": "the same batch with nothing else in flight (the last 12 of a 0.15 s run of single batches after the timed region, HIP events "
@@ -712,6 +712,8 @@ def main() -> int:
                     help="BGR configurations (c4: the sharded stream): add the streamed leg -- every rank feeds its frames from "
                          "page-locked host memory through imgproc_submit_pinned; reported under `streamed`, never as `value`")
     ap.add_argument("--no-numa", action="store_true", help="leave the CPU affinity alone (default: pin each rank to its GPU's NUMA node)")
+    ap.add_argument("--no-alone", dest="alone", action="store_false",
+                    help="skip the one-batch-at-a-time leg after the timed region (the profiling scripts: its launches would mix into the per-kernel averages)")
     ap.add_argument("--no-check", dest="check", action="store_false",
                     help="skip the oracle check of one frame of the last batch (it runs after the timed region by default)")
     ap.add_argument("--check", dest="check", action="store_true", help="(default) verify one frame of the last batch against the oracle")

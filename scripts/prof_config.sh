@@ -7,7 +7,7 @@ cfg=$1; tag=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 out=gpurun_out/$tag
 rm -rf $out && mkdir -p $out
-BENCH="python3 bench.py --config $cfg --no-cpu-baseline --no-streamed --no-check $*"
+BENCH="python3 bench.py --config $cfg --no-cpu-baseline --no-streamed --no-check --no-alone $*"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $BENCH > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "grbm GRBM_GUI_ACTIVE" \
             "sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
